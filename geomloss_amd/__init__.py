@@ -1,0 +1,17 @@
+"""geomloss_amd — MI355X-native Sinkhorn / kernel losses behind geomloss's ``SamplesLoss`` API.
+
+Drop-in for the hot path of jeanfeydy/geomloss 0.3.1::
+
+    from geomloss_amd import SamplesLoss          # instead of: from geomloss import SamplesLoss
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online")(x, y)
+
+The soft-min (log-sum-exp) and kernel reductions over the implicit N x M cost matrix run as
+hand-written gfx950 HIP kernels (``geomloss_amd/csrc``, C-ABI in ``include/glhip.h``).
+"""
+
+__version__ = "0.1.0"
+
+from .samples_loss import SamplesLoss
+from . import hip
+
+__all__ = ["SamplesLoss", "hip"]

@@ -1,0 +1,297 @@
+// glhip_api.hip — the C-ABI of libgeomloss_hip.so (see include/glhip.h): argument checks,
+// scale factors, kernel selection, asynchronous launch.  gfx950 only.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "glhip_generic.h"
+#include "glhip_kconv_ops.h"
+#include "glhip_softmin_ops.h"
+
+using namespace glhip;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GLHIP_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return GLHIP_OK;
+}
+
+int check_common(const char* fn, const void* x, const void* y, const void* s, int B, int N, int M, int D,
+                 int in_dtype, const int32_t* ri, const int32_t* si, const int32_t* rj, int n_ranges) {
+    if (!x || !y || !s) return fail(GLHIP_EINVAL, "%s: NULL input pointer", fn);
+    if (B < 0 || N < 0 || M < 0 || D < 1) return fail(GLHIP_EINVAL, "%s: bad sizes B=%d N=%d M=%d D=%d", fn, B, N, M, D);
+    if (in_dtype != GLHIP_F32 && in_dtype != GLHIP_BF16) return fail(GLHIP_EINVAL, "%s: bad in_dtype %d", fn, in_dtype);
+    if (n_ranges < 0) return fail(GLHIP_EINVAL, "%s: n_ranges < 0", fn);
+    if (n_ranges > 0) {
+        if (!ri || !si || !rj) return fail(GLHIP_EINVAL, "%s: block-sparse mode needs ranges_i, slices_i, redranges_j", fn);
+        if (B != 1) return fail(GLHIP_EUNSUPPORTED, "%s: block-sparse mode requires B == 1 (got %d)", fn, B);
+    }
+    if (B > 65535) return fail(GLHIP_EUNSUPPORTED, "%s: B=%d exceeds the grid.y limit 65535", fn, B);
+    return GLHIP_OK;
+}
+
+// rows per thread: 2 keeps the LDS read rate at half a ds_read_b128 per row-column step while leaving
+// enough workgroups to fill 256 CUs; small problems use 1 to expose more workgroups.
+inline bool use_two_rows(int B, int N, int n_ranges) {
+    if (n_ranges > 0) return true;
+    const long blocks2 = (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
+    return blocks2 >= 1024;
+}
+
+// ---- softmin ---------------------------------------------------------------------------------------
+
+template <int D, int P, bool DIRECT, bool BWD, typename T>
+void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                      hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges)) {
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, st);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, st);
+    } else {
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, st);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, st);
+    }
+}
+
+template <int D, bool BWD, typename T>
+void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
+                      bool direct, hipStream_t st) {
+    if (p == 1) launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+    else if (direct) launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+    else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+}
+
+template <bool BWD, typename T>
+int softmin_typed(const void* x, const void* y, const float* h, float* out, const float* fwd, const float* g,
+                  float* gx, int B, int N, int M, int D, float eps, int p, const Ranges& rg, int n_ranges,
+                  int flags, hipStream_t st) {
+    const float s2 = kLog2e / eps;
+    const float out_scale = -eps * kLn2;
+    if (D <= 3) {
+        const bool direct = (flags & GLHIP_FLAG_DIRECT) != 0;
+        SoftminParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.h = h;
+        prm.out = out;
+        prm.fwd = fwd;
+        prm.g = g;
+        prm.gx = gx;
+        prm.s2 = s2;
+        prm.t = (p == 1) ? s2 : std::sqrt(0.5f * s2);
+        prm.inv_t = 1.0f / prm.t;
+        prm.out_scale = out_scale;
+        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
+        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
+        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
+    } else {
+        if (BWD && D > kGenericMaxGradD)
+            return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
+                        D, kGenericMaxGradD);
+        GenericParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.s = h;
+        prm.out = out;
+        prm.fwd = fwd;
+        prm.g = g;
+        prm.gx = gx;
+        prm.dscale = (p == 1) ? s2 : 0.5f * s2;
+        prm.out_scale = out_scale;
+        prm.gscale = 1.f;
+        const bool sp = n_ranges > 0;
+        dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
+#define GL_LAUNCH(MODE, SP) \
+    hipLaunchKernelGGL((generic_kernel<MODE, BWD, SP, T>), grid, dim3(kBlock), 0, st, prm, rg, N, M, D)
+        if (p == 2) { if (sp) GL_LAUNCH(GM_SOFTMIN_P2, true); else GL_LAUNCH(GM_SOFTMIN_P2, false); }
+        else        { if (sp) GL_LAUNCH(GM_SOFTMIN_P1, true); else GL_LAUNCH(GM_SOFTMIN_P1, false); }
+#undef GL_LAUNCH
+    }
+    return GLHIP_OK;
+}
+
+// ---- kernel products ---------------------------------------------------------------------------------
+
+template <int KIND, int D, bool BWD, typename T>
+void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges)) launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, st);
+    else launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, st);
+}
+
+template <int KIND, bool BWD, typename T>
+void launch_conv_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int D,
+                   hipStream_t st) {
+    if (D == 1) launch_conv_r<KIND, 1, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+    else if (D == 2) launch_conv_r<KIND, 2, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+    else launch_conv_r<KIND, 3, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+}
+
+template <bool BWD, typename T>
+int conv_typed(int kind, const void* x, const void* y, const float* v, float* out, const float* g, float* gx,
+               int B, int N, int M, int D, float blur, const Ranges& rg, int n_ranges, hipStream_t st) {
+    if (D <= 3) {
+        ConvParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.v = v;
+        prm.out = out;
+        prm.g = g;
+        prm.gx = gx;
+        if (kind == GLHIP_GAUSSIAN) {
+            prm.t = std::sqrt(0.5f * kLog2e) / blur;
+            prm.gscale = -1.0f / (prm.t * blur * blur);
+            launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+        } else if (kind == GLHIP_LAPLACIAN) {
+            prm.t = kLog2e / blur;
+            prm.gscale = -1.0f / blur;
+            launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+        } else {
+            prm.t = 1.0f;
+            prm.gscale = -1.0f;
+            launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+        }
+    } else {
+        if (BWD && D > kGenericMaxGradD)
+            return fail(GLHIP_EUNSUPPORTED, "kernel_conv_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
+                        D, kGenericMaxGradD);
+        GenericParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.s = v;
+        prm.out = out;
+        prm.fwd = nullptr;
+        prm.g = g;
+        prm.gx = gx;
+        prm.out_scale = 1.f;
+        const bool sp = n_ranges > 0;
+        dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
+#define GL_LAUNCH(MODE, SP) \
+    hipLaunchKernelGGL((generic_kernel<MODE, BWD, SP, T>), grid, dim3(kBlock), 0, st, prm, rg, N, M, D)
+        if (kind == GLHIP_GAUSSIAN) {
+            prm.dscale = 0.5f * kLog2e / (blur * blur);
+            prm.gscale = -1.0f / (blur * blur);
+            if (sp) GL_LAUNCH(GM_GAUSS, true); else GL_LAUNCH(GM_GAUSS, false);
+        } else if (kind == GLHIP_LAPLACIAN) {
+            prm.dscale = kLog2e / blur;
+            prm.gscale = -1.0f / blur;
+            if (sp) GL_LAUNCH(GM_LAPLACE, true); else GL_LAUNCH(GM_LAPLACE, false);
+        } else {
+            prm.dscale = 1.f;
+            prm.gscale = -1.0f;
+            if (sp) GL_LAUNCH(GM_ENERGY, true); else GL_LAUNCH(GM_ENERGY, false);
+        }
+#undef GL_LAUNCH
+    }
+    return GLHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glhip_version(void) { return GLHIP_VERSION; }
+
+const char* glhip_last_error(void) { return g_err; }
+
+int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, int B, int N, int M, int D,
+                      float eps, int p, int in_dtype, const int32_t* ranges_i, const int32_t* slices_i,
+                      const int32_t* redranges_j, int n_ranges, int flags, void* stream) {
+    int rc = check_common("glhip_softmin_fwd", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (!out) return fail(GLHIP_EINVAL, "glhip_softmin_fwd: NULL out");
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_fwd: eps must be > 0");
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd: p must be 1 or 2 (got %d)", p);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = (in_dtype == GLHIP_F32)
+             ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, flags, st)
+             : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, flags, st);
+    return rc ? rc : check_launch("glhip_softmin_fwd");
+}
+
+int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const float* out, const float* grad_out,
+                        float* grad_x, int B, int N, int M, int D, float eps, int p, int in_dtype,
+                        const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                        int flags, void* stream) {
+    int rc = check_common("glhip_softmin_bwd_x", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (!out || !grad_out || !grad_x) return fail(GLHIP_EINVAL, "glhip_softmin_bwd_x: NULL out / grad_out / grad_x");
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_bwd_x: eps must be > 0");
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_bwd_x: p must be 1 or 2 (got %d)", p);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = (in_dtype == GLHIP_F32)
+             ? softmin_typed<true, float>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, flags, st)
+             : softmin_typed<true, bf16_t>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, flags, st);
+    return rc ? rc : check_launch("glhip_softmin_bwd_x");
+}
+
+int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v, float* out, int B, int N, int M,
+                          int D, float blur, int in_dtype, const int32_t* ranges_i, const int32_t* slices_i,
+                          const int32_t* redranges_j, int n_ranges, int flags, void* stream) {
+    (void)flags;
+    int rc = check_common("glhip_kernel_conv_fwd", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (!out) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: NULL out");
+    if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: bad kind %d", kind);
+    if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: blur must be > 0");
+    if (B == 0 || N == 0) return GLHIP_OK;
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = (in_dtype == GLHIP_F32)
+             ? conv_typed<false, float>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, st)
+             : conv_typed<false, bf16_t>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, st);
+    return rc ? rc : check_launch("glhip_kernel_conv_fwd");
+}
+
+int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float* v, const float* g, float* grad_x,
+                            int B, int N, int M, int D, float blur, int in_dtype, const int32_t* ranges_i,
+                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, int flags,
+                            void* stream) {
+    (void)flags;
+    int rc = check_common("glhip_kernel_conv_bwd_x", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (!g || !grad_x) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: NULL g / grad_x");
+    if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: bad kind %d", kind);
+    if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: blur must be > 0");
+    if (B == 0 || N == 0) return GLHIP_OK;
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = (in_dtype == GLHIP_F32)
+             ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, st)
+             : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, st);
+    return rc ? rc : check_launch("glhip_kernel_conv_bwd_x");
+}
+
+int glhip_softmin_dense_fwd(const float* C, const float* h, float* out, int B, int N, int M, float eps,
+                            void* stream) {
+    if (!C || !h || !out) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: NULL pointer");
+    if (B < 0 || N < 0 || M < 0) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: bad sizes");
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: eps must be > 0");
+    if (B > 65535) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_dense_fwd: B=%d exceeds the grid.y limit", B);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows_per_block = (kBlock / 64) * kDenseRows;
+    dim3 grid((N + rows_per_block - 1) / rows_per_block, B, 1);
+    const float s2 = kLog2e / eps, out_scale = -eps * kLn2;
+    const bool vec = (M % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(h)) % 16 == 0);
+    if (vec) hipLaunchKernelGGL((softmin_dense_kernel<true>), grid, dim3(kBlock), 0, st, C, h, out, N, M, s2, out_scale);
+    else hipLaunchKernelGGL((softmin_dense_kernel<false>), grid, dim3(kBlock), 0, st, C, h, out, N, M, s2, out_scale);
+    return check_launch("glhip_softmin_dense_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// glhip_kconv_ops.h — row operators for kernel-matrix x vector products
+//   out_i = sum_j k(x_i, y_j) v_j,  k in {gaussian, laplacian, energy}
+// and for their gradient with respect to the row points.  Plugged into mapreduce_kernel.
+//
+// All three kernels are radial, and all three are evaluated on explicit differences
+// (xs_d - ys_d) of centred, pre-scaled coordinates — no |x|^2 - 2x.y + |y|^2 expansion, so the
+// laplacian / energy kernels do not inherit the cancellation error of the dense reference code
+// near x = y (utils.py:42-61 clamps that error at 1e-8 instead).
+//   gaussian : t = sqrt(log2(e)/2) / blur,  k = 2^(-|xs-ys|^2)
+//   laplacian: t = log2(e) / blur,          k = 2^(-|xs-ys|)
+//   energy   : t = 1,                       k = -|xs-ys|
+// LDS record: { ys_0 .. ys_{D-1}, v_j }.
+#pragma once
+
+#include "glhip_mapreduce.h"
+
+namespace glhip {
+
+template <typename T>
+struct ConvParams {
+    const T* x;        // (B,N,D)
+    const T* y;        // (B,M,D)
+    const float* v;    // (B,M)
+    float* out;        // fwd: (B,N)
+    const float* g;    // bwd: (B,N)
+    float* gx;         // bwd: (B,N,D)
+    float t;           // coordinate pre-scale
+    float gscale;      // bwd: factor applied to the accumulated direction sum
+};
+
+template <int KIND>
+__device__ __forceinline__ float radial_kernel(float d2) {
+    if (KIND == GLHIP_GAUSSIAN) return fast_exp2(-d2);
+    if (KIND == GLHIP_LAPLACIAN) return fast_exp2(-fast_sqrt(d2));
+    return -fast_sqrt(d2);
+}
+
+template <int KIND, int D_, int R, typename T, bool BWD>
+struct ConvOp {
+    static constexpr int kDim = D_;
+    static constexpr int kRows = R;
+    using Params = ConvParams<T>;
+    struct RowState {
+        float a[R][D_];
+        float acc[R][BWD ? D_ : 1];
+    };
+
+    static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
+        load_point<D_, T>(p.x, (long)b * N + row0, c);
+    }
+
+    static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                     int tid, const float (&c)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = min(row0 + r * kBlock + tid, row_end - 1);
+            float xi[D_];
+            load_point<D_, T>(p.x, (long)b * N + i, xi);
+#pragma unroll
+            for (int d = 0; d < D_; ++d) st.a[r][d] = (xi[d] - c[d]) * p.t;
+#pragma unroll
+            for (int d = 0; d < (BWD ? D_ : 1); ++d) st.acc[r][d] = 0.f;
+        }
+    }
+
+    static __device__ __forceinline__ Rec<D_> make_record(const Params& p, int b, int M, int j, const float (&c)[D_]) {
+        float yj[D_];
+        load_point<D_, T>(p.y, (long)b * M + j, yj);
+        Rec<D_> rec;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) rec.c[d] = (yj[d] - c[d]) * p.t;
+        rec_tail<D_>(rec) = p.v[(long)b * M + j];
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+
+    static __device__ __forceinline__ Rec<D_> neutral_record() {
+        Rec<D_> rec;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) rec.c[d] = 0.f;
+        rec_tail<D_>(rec) = 0.f;   // zero weight: contributes nothing
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+
+    static __device__ __forceinline__ void consume(RowState& st, const Rec<D_>* __restrict__ recs) {
+        Rec<D_> rc[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) rc[c] = recs[c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                float df[D_];
+                float d2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D_; ++d) {
+                    df[d] = st.a[r][d] - rc[c].c[d];
+                    d2 = __builtin_fmaf(df[d], df[d], d2);
+                }
+                const float vj = rec_tail<D_>(rc[c]);
+                if (!BWD) {
+                    st.acc[r][0] = __builtin_fmaf(radial_kernel<KIND>(d2), vj, st.acc[r][0]);
+                } else {
+                    // weight of the direction (xs - ys):  gaussian k ; laplacian k/|.| ; energy 1/|.|
+                    float w;
+                    if (KIND == GLHIP_GAUSSIAN) {
+                        w = vj * fast_exp2(-d2);
+                    } else {
+                        const float rs = (d2 > 0.f) ? fast_rsq(d2) : 0.f;
+                        w = (KIND == GLHIP_LAPLACIAN) ? vj * rs * fast_exp2(-d2 * rs) : vj * rs;
+                    }
+#pragma unroll
+                    for (int d = 0; d < D_; ++d) st.acc[r][d] = __builtin_fmaf(w, df[d], st.acc[r][d]);
+                }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void finish_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                       int tid, const float (&)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r * kBlock + tid;
+            if (i < row_end) {
+                if (!BWD) {
+                    p.out[(long)b * N + i] = st.acc[r][0];
+                } else {
+                    const float gi = p.g[(long)b * N + i] * p.gscale;
+#pragma unroll
+                    for (int d = 0; d < D_; ++d) p.gx[((long)b * N + i) * D_ + d] = gi * st.acc[r][d];
+                }
+            }
+        }
+    }
+};
+
+}  // namespace glhip

@@ -1,0 +1,284 @@
+// glhip_softmin_ops.h — row operators for the soft-C-transform (log-sum-exp over columns)
+// and its gradient with respect to the row points.  Plugged into mapreduce_kernel.
+//
+// Everything is evaluated in base 2 so that the inner loop is FMA chain -> v_exp_f32:
+//   u_ij = log2(e) * ( h_j - C(x_i, y_j) / eps ),   LSE2_i = log2 sum_j 2^u_ij,
+//   out_i = -eps * ln(2) * LSE2_i.
+//
+// Two evaluation forms of u_ij:
+//   EXPANDED (p = 2 only, default):  with xt = x - c, yt = y - c, s2 = log2(e)/eps,
+//       u_ij = r_i + [ H_j + a_i . yt_j ],   a_i = s2 * xt_i,  r_i = -s2/2 |xt_i|^2,
+//       H_j = log2(e) h_j - s2/2 |yt_j|^2                       -> 3 FMAs per pair (D = 3)
+//     r_i is constant along the row and is added after the reduction.
+//   DIRECT (p = 1, or p = 2 with GLHIP_FLAG_DIRECT): coordinates pre-scaled by t,
+//       p = 2: t = sqrt(s2/2), u_ij = H_j - sum_d (xs_d - ys_d)^2
+//       p = 1: t = s2,         u_ij = H_j - sqrt( sum_d (xs_d - ys_d)^2 )      (KeOps' Norm2, no clamp)
+//
+// The running maximum is exact (updated every kChunk columns), so no threshold / rescale branch exists.
+#pragma once
+
+#include "glhip_mapreduce.h"
+
+namespace glhip {
+
+template <typename T>
+struct SoftminParams {
+    const T* x;        // (B,N,D)
+    const T* y;        // (B,M,D)
+    const float* h;    // (B,M)
+    float* out;        // fwd: result (B,N);          bwd: unused
+    const float* fwd;  // bwd: saved forward result (B,N)
+    const float* g;    // bwd: grad_out (B,N)
+    float* gx;         // bwd: grad_x (B,N,D)
+    float s2;          // log2(e) / eps
+    float t;           // coordinate pre-scale of the DIRECT form
+    float inv_t;       // 1 / t
+    float out_scale;   // -eps * ln(2)
+};
+
+// ---- shared pieces ---------------------------------------------------------------------------
+
+template <int D, typename T>
+__device__ __forceinline__ void centre_of(const T* __restrict__ x, int b, int N, int row0, float (&c)[D]) {
+    // row0 is workgroup-uniform, so this is a scalar (SMEM) load shared by the whole workgroup
+    load_point<D, T>(x, (long)b * N + row0, c);
+}
+
+// online log-sum-exp update with kChunk fresh exponents
+__device__ __forceinline__ void lse_update(float& m, float& s, const float (&u)[kChunk]) {
+    float cm = u[0];
+#pragma unroll
+    for (int c = 1; c < kChunk; ++c) cm = fmaxf(cm, u[c]);
+    const float mn = fmaxf(m, cm);
+    s *= fast_exp2(m - mn);
+    m = mn;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < kChunk; c += 2) {
+        s0 += fast_exp2(u[c] - mn);
+        s1 += fast_exp2(u[c + 1] - mn);
+    }
+    s += s0 + s1;
+}
+
+// u for one (row, record) pair
+template <int D, int P, bool DIRECT>
+__device__ __forceinline__ float pair_exponent(const float (&a)[D], const Rec<D>& r) {
+    if (!DIRECT) {
+        float u = rec_tail<D>(r);
+#pragma unroll
+        for (int d = D - 1; d >= 0; --d) u = __builtin_fmaf(a[d], r.c[d], u);
+        return u;
+    } else if (P == 2) {
+        float u = rec_tail<D>(r);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float df = a[d] - r.c[d];
+            u = __builtin_fmaf(-df, df, u);
+        }
+        return u;
+    } else {
+        float d2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float df = a[d] - r.c[d];
+            d2 = __builtin_fmaf(df, df, d2);
+        }
+        return rec_tail<D>(r) - fast_sqrt(d2);
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------
+
+template <int D_, int P, bool DIRECT, int R, typename T>
+struct SoftminFwdOp {
+    static constexpr int kDim = D_;
+    static constexpr int kRows = R;
+    using Params = SoftminParams<T>;
+    struct RowState {
+        float a[R][D_];   // scaled, centred row coordinates
+        float r[R];       // row constant of the expanded form (0 for DIRECT)
+        float m[R], s[R];
+    };
+
+    static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
+        centre_of<D_, T>(p.x, b, N, row0, c);
+    }
+
+    static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                     int tid, const float (&c)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = min(row0 + r * kBlock + tid, row_end - 1);   // clamp: idle lanes redo a valid row
+            float xi[D_];
+            load_point<D_, T>(p.x, (long)b * N + i, xi);
+            float n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D_; ++d) {
+                const float xt = xi[d] - c[d];
+                n2 = __builtin_fmaf(xt, xt, n2);
+                st.a[r][d] = xt * (DIRECT ? p.t : p.s2);
+            }
+            st.r[r] = DIRECT ? 0.f : -0.5f * p.s2 * n2;
+            st.m[r] = kNegBig;
+            st.s[r] = 0.f;
+        }
+    }
+
+    static __device__ __forceinline__ Rec<D_> make_record(const Params& p, int b, int M, int j, const float (&c)[D_]) {
+        float yj[D_];
+        load_point<D_, T>(p.y, (long)b * M + j, yj);
+        Rec<D_> rec;
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) {
+            const float yt = yj[d] - c[d];
+            n2 = __builtin_fmaf(yt, yt, n2);
+            rec.c[d] = DIRECT ? yt * p.t : yt;
+        }
+        const float hj = p.h[(long)b * M + j] * kLog2e;
+        rec_tail<D_>(rec) = DIRECT ? hj : __builtin_fmaf(-0.5f * p.s2, n2, hj);
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+
+    static __device__ __forceinline__ Rec<D_> neutral_record() {
+        Rec<D_> rec;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) rec.c[d] = 0.f;
+        rec_tail<D_>(rec) = kNegBig;
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+
+    static __device__ __forceinline__ void consume(RowState& st, const Rec<D_>* __restrict__ recs) {
+        Rec<D_> rc[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) rc[c] = recs[c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float u[kChunk];
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) u[c] = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c]);
+            lse_update(st.m[r], st.s[r], u);
+        }
+    }
+
+    static __device__ __forceinline__ void finish_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                       int tid, const float (&)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r * kBlock + tid;
+            if (i < row_end) {
+                const float lse2 = st.r[r] + st.m[r] + fast_log2(st.s[r]);
+                p.out[(long)b * N + i] = p.out_scale * lse2;
+            }
+        }
+    }
+};
+
+// ---- backward with respect to x ------------------------------------------------------------------
+//   P_ij = 2^(u_ij - LSE2_i);  p = 2: grad_x_i = g_i (x_i - sum_j P_ij y_j / sum_j P_ij)
+//                              p = 1: grad_x_i = g_i  sum_j P_ij (x_i - y_j)/|x_i - y_j| / sum_j P_ij
+
+template <int D_, int P, bool DIRECT, int R, typename T>
+struct SoftminBwdOp {
+    static constexpr int kDim = D_;
+    static constexpr int kRows = R;
+    using Params = SoftminParams<T>;
+    struct RowState {
+        float a[R][D_];
+        float l[R];        // LSE2_i minus the row constant r_i
+        float acc[R][D_];
+        float sw[R];
+    };
+
+    static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
+        centre_of<D_, T>(p.x, b, N, row0, c);
+    }
+
+    static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                     int tid, const float (&c)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = min(row0 + r * kBlock + tid, row_end - 1);
+            float xi[D_];
+            load_point<D_, T>(p.x, (long)b * N + i, xi);
+            float n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D_; ++d) {
+                const float xt = xi[d] - c[d];
+                n2 = __builtin_fmaf(xt, xt, n2);
+                st.a[r][d] = xt * (DIRECT ? p.t : p.s2);
+                st.acc[r][d] = 0.f;
+            }
+            const float lse2 = p.fwd[(long)b * N + i] / p.out_scale;   // out = out_scale * LSE2
+            st.l[r] = DIRECT ? lse2 : lse2 + 0.5f * p.s2 * n2;          // LSE2 - r_i
+            st.sw[r] = 0.f;
+        }
+    }
+
+    static __device__ __forceinline__ Rec<D_> make_record(const Params& p, int b, int M, int j, const float (&c)[D_]) {
+        return SoftminFwdOp<D_, P, DIRECT, R, T>::make_record(p, b, M, j, c);
+    }
+    static __device__ __forceinline__ Rec<D_> neutral_record() {
+        return SoftminFwdOp<D_, P, DIRECT, R, T>::neutral_record();
+    }
+
+    static __device__ __forceinline__ void consume(RowState& st, const Rec<D_>* __restrict__ recs) {
+        Rec<D_> rc[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) rc[c] = recs[c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                const float u = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c]);
+                const float w = fast_exp2(u - st.l[r]);
+                st.sw[r] += w;
+                if (P == 2) {
+#pragma unroll
+                    for (int d = 0; d < D_; ++d) st.acc[r][d] = __builtin_fmaf(w, rc[c].c[d], st.acc[r][d]);
+                } else {
+                    float df[D_];
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D_; ++d) {
+                        df[d] = st.a[r][d] - rc[c].c[d];
+                        d2 = __builtin_fmaf(df[d], df[d], d2);
+                    }
+                    const float wr = (d2 > 0.f) ? w * fast_rsq(d2) : 0.f;
+#pragma unroll
+                    for (int d = 0; d < D_; ++d) st.acc[r][d] = __builtin_fmaf(wr, df[d], st.acc[r][d]);
+                }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void finish_rows(const Params& p, int b, int N, int row0, int row_end,
+                                                       int tid, const float (&)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r * kBlock + tid;
+            if (i < row_end) {
+                const float gi = p.g[(long)b * N + i];
+                const float inv = (st.sw[r] > 0.f) ? 1.0f / st.sw[r] : 0.f;
+#pragma unroll
+                for (int d = 0; d < D_; ++d) {
+                    float v;
+                    if (P == 2) {
+                        // rows: a = xt * scale; records: yt (expanded) or yt * t (direct)
+                        const float xt = st.a[r][d] * (DIRECT ? p.inv_t : 1.0f / p.s2);
+                        const float ybar = st.acc[r][d] * inv * (DIRECT ? p.inv_t : 1.0f);
+                        v = xt - ybar;
+                    } else {
+                        v = st.acc[r][d] * inv;
+                    }
+                    p.gx[((long)b * N + i) * D_ + d] = gi * v;
+                }
+            }
+        }
+    }
+};
+
+}  // namespace glhip

@@ -1,0 +1,301 @@
+"""ctypes binding of ``libgeomloss_hip.so`` (C-ABI: ``include/glhip.h``) and the autograd
+functions built on it.
+
+This module is the only place where Python touches the HIP kernels.  It plays the role that
+``pykeops.torch`` plays for the reference (``generic_logsumexp`` at
+``_legacy/sinkhorn_samples.py:322-334,432-442``; ``LazyTensor @ v`` at
+``_legacy/kernel_samples.py:128-137``).  There is no fallback: if the shared library is missing or
+a tensor is not on a GPU, the call raises.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
+
+GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
+KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
+F32, BF16 = 0, 1
+FLAG_DIRECT = 1
+
+# every symbol include/glhip.h declares, with its ctypes signature
+_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_RANGES = [_vp, _vp, _vp, _c_int]
+SIGNATURES = {
+    "glhip_version": (_c_int, []),
+    "glhip_last_error": (ctypes.c_char_p, []),
+    "glhip_softmin_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int]
+                          + _RANGES + [_c_int, _vp]),
+    "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
+                                     _c_int] + _RANGES + [_c_int, _vp]),
+    "glhip_kernel_conv_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int]
+                              + _RANGES + [_c_int, _vp]),
+    "glhip_kernel_conv_bwd_x": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
+                                         _c_int] + _RANGES + [_c_int, _vp]),
+    "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads (once) and returns the shared library; raises ``RuntimeError`` if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"geomloss_amd: the HIP extension {path} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C geomloss_amd/csrc`). "
+            "The 'online' and 'multiscale' backends have no CPU or PyTorch fallback."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def library_available():
+    return os.path.exists(LIB_PATH)
+
+
+def _check(rc, lib):
+    if rc != 0:
+        msg = lib.glhip_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -2:
+            raise NotImplementedError(msg)
+        raise RuntimeError(msg)
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _points(t, name):
+    """Point clouds go to the kernels as contiguous fp32 or bf16; other float types are widened/narrowed to fp32."""
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"geomloss_amd: '{name}' lives on {t.device}; the HIP backends ('online', 'multiscale') need GPU tensors. "
+            "Use backend='tensorized' for CPU tensors."
+        )
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t.contiguous()
+
+
+def _dtype_code(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+class BlockRanges:
+    """Block-sparse reduction pattern in the KeOps convention (see ``include/glhip.h``), both orientations.
+
+    Stands in for the 6-tuple returned by ``pykeops.torch.cluster.from_matrix``
+    (``_legacy/sinkhorn_samples.py:515``); ``.t()`` is ``swap_axes`` (``:529``).
+    """
+
+    def __init__(self, ranges_i, slices_i, redranges_j, ranges_j, slices_j, redranges_i):
+        self.ranges_i, self.slices_i, self.redranges_j = ranges_i, slices_i, redranges_j
+        self.ranges_j, self.slices_j, self.redranges_i = ranges_j, slices_j, redranges_i
+
+    def t(self):
+        return BlockRanges(self.ranges_j, self.slices_j, self.redranges_i,
+                           self.ranges_i, self.slices_i, self.redranges_j)
+
+    def c_args(self):
+        n = int(self.ranges_i.shape[0])
+        return [ctypes.c_void_p(self.ranges_i.data_ptr()), ctypes.c_void_p(self.slices_i.data_ptr()),
+                ctypes.c_void_p(self.redranges_j.data_ptr()), n]
+
+
+_NO_RANGES = [None, None, None, 0]
+
+
+def _range_args(ranges, B):
+    if ranges is None:
+        return _NO_RANGES
+    if B != 1:
+        raise NotImplementedError("Block-sparse reductions are only implemented for a single (un-batched) problem.")
+    return ranges.c_args()
+
+
+def _as_batched(x, y, s):
+    """(N,D),(M,D),(M,) -> (1,N,D),(1,M,D),(1,M); batched inputs pass through."""
+    if x.dim() == 2:
+        return x.unsqueeze(0), y.unsqueeze(0), s.reshape(1, -1), False
+    return x, y, s.reshape(x.shape[0], -1), True
+
+
+# ----------------------------------------------------------------------------------------------
+#  raw launches
+# ----------------------------------------------------------------------------------------------
+
+def softmin_fwd_raw(x, y, h, eps, p=2, ranges=None, flags=0):
+    """x (B,N,D), y (B,M,D) fp32|bf16 contiguous CUDA; h (B,M) fp32 -> (B,N) fp32."""
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.glhip_softmin_fwd(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, D,
+                                   float(eps), int(p), _dtype_code(x), *_range_args(ranges, B), int(flags), _stream(x))
+    _check(rc, lib)
+    return out
+
+
+def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.glhip_softmin_bwd_x(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), grad_out.data_ptr(),
+                                     gx.data_ptr(), B, N, M, D, float(eps), int(p), _dtype_code(x),
+                                     *_range_args(ranges, B), int(flags), _stream(x))
+    _check(rc, lib)
+    return gx
+
+
+def kernel_conv_fwd_raw(kind, x, y, v, blur, ranges=None):
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.glhip_kernel_conv_fwd(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), out.data_ptr(), B, N, M, D,
+                                       float(blur), _dtype_code(x), *_range_args(ranges, B), 0, _stream(x))
+    _check(rc, lib)
+    return out
+
+
+def kernel_conv_bwd_x_raw(kind, x, y, v, g, blur, ranges=None):
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.glhip_kernel_conv_bwd_x(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(),
+                                         gx.data_ptr(), B, N, M, D, float(blur), _dtype_code(x),
+                                         *_range_args(ranges, B), 0, _stream(x))
+    _check(rc, lib)
+    return gx
+
+
+def softmin_dense_fwd_raw(C, h, eps):
+    lib = load_library()
+    B, N, M = C.shape
+    out = torch.empty((B, N), dtype=torch.float32, device=C.device)
+    with torch.cuda.device(C.device):
+        rc = lib.glhip_softmin_dense_fwd(C.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, float(eps), _stream(C))
+    _check(rc, lib)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+#  autograd functions
+# ----------------------------------------------------------------------------------------------
+
+class _Softmin(torch.autograd.Function):
+    """f_i = -eps log sum_j exp(h_j - C(x_i,y_j)/eps); differentiable in x only, like the reference's call sites."""
+
+    @staticmethod
+    def forward(ctx, x, y, h, eps, p, ranges, flags):
+        xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
+        if yb.dtype != xb.dtype:
+            yb = yb.to(xb.dtype)
+        out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
+        ctx.save_for_backward(xb, yb, hb, out)
+        ctx.cfg = (eps, p, ranges, flags, x.shape, x.dtype)
+        return out if batched else out.view(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError(
+                "geomloss_amd: the HIP soft-min is differentiable with respect to its first point cloud only "
+                "(the Sinkhorn loop detaches the second cloud and the dual vector)."
+            )
+        xb, yb, hb, out = ctx.saved_tensors
+        eps, p, ranges, flags, xshape, xdtype = ctx.cfg
+        g = grad_out.reshape(out.shape).float().contiguous()
+        gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
+        return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None
+
+
+def softmin(eps, x, y, h, p=2, ranges=None, flags=0):
+    """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32."""
+    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags))
+
+
+class _KernelConv(torch.autograd.Function):
+    """out_i = sum_j k(x_i,y_j) v_j, differentiable in x, y and v."""
+
+    @staticmethod
+    def forward(ctx, kind, x, y, v, blur, ranges):
+        xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
+        if yb.dtype != xb.dtype:
+            yb = yb.to(xb.dtype)
+        out = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges)
+        ctx.save_for_backward(xb, yb, vb)
+        ctx.cfg = (kind, blur, ranges, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
+        return out if batched else out.view(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xb, yb, vb = ctx.saved_tensors
+        kind, blur, ranges, xs, ys, vs, xdt, ydt, vdt = ctx.cfg
+        g = grad_out.reshape(xb.shape[0], -1).float().contiguous()
+        rt = None if ranges is None else ranges.t()
+        gx = gy = gv = None
+        if ctx.needs_input_grad[1]:
+            gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges).reshape(xs).to(xdt)
+        if ctx.needs_input_grad[2]:
+            gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt).reshape(ys).to(ydt)
+        if ctx.needs_input_grad[3]:
+            gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt).reshape(vs).to(vdt)
+        return None, gx, gy, gv, None, None
+
+
+def kernel_conv(kind, x, y, v, blur=0.05, ranges=None):
+    """Kernel-matrix x vector product on the GPU; ``kind`` is a name or a GLHIP_* code."""
+    kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
+    return _KernelConv.apply(kind, x, y, v, 1.0 if blur is None else float(blur), ranges)
+
+
+class _SoftminDense(torch.autograd.Function):
+    """Row-wise soft-min of an explicit cost matrix (the tensorized backend on GPU tensors)."""
+
+    @staticmethod
+    def forward(ctx, C, h, eps):
+        Cb, hb = C.float().contiguous(), h.float().contiguous()
+        out = softmin_dense_fwd_raw(Cb, hb, eps)
+        ctx.save_for_backward(Cb, hb, out)
+        ctx.eps = eps
+        ctx.dtypes = (C.dtype, h.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        Cb, hb, out = ctx.saved_tensors
+        eps = ctx.eps
+        # d out_i / d C_ij = P_ij,  d out_i / d h_j = -eps P_ij,  P = softmax_j(h_j - C_ij/eps)
+        P = torch.exp(hb[:, None, :] - Cb / eps + (out / eps)[:, :, None]) * grad_out[:, :, None]
+        gC = P.to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        gh = (-eps * P.sum(1)).to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None
+        return gC, gh, None
+
+
+def softmin_dense(eps, C, h):
+    return _SoftminDense.apply(C, h, float(eps))

@@ -1,0 +1,171 @@
+"""Kernel norms (MMDs) between sampled measures: ``SamplesLoss("gaussian" | "laplacian" | "energy")``.
+
+    Loss(a, b) = 1/2 <a, k*a> + 1/2 <b, k*b> - <a, k*b>,
+    k(x,y) = exp(-|x-y|^2 / 2 blur^2) | exp(-|x-y| / blur) | -|x-y|.
+
+Mirror of the reference's ``_legacy/kernel_samples.py``.  ``kernel_tensorized`` builds dense kernel
+matrices with PyTorch (any device); ``kernel_online`` and ``kernel_multiscale`` evaluate the three
+kernel-matrix x vector products with the HIP kernel ``glhip_kernel_conv_fwd`` (dense / block-sparse)
+and never materialise a matrix.
+"""
+
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import hip
+from .cluster import cluster_ranges_centroids, from_matrix, grid_cluster, sort_clusters
+from .utils import distances, scal, squared_distances
+
+
+class DoubleGrad(torch.autograd.Function):
+    """Identity whose gradient is doubled: lets the symmetric terms <a, K_xx a> be built with one detached side (``:43-54``)."""
+
+    @staticmethod
+    def forward(ctx, input):
+        return input
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return 2 * grad_output
+
+
+def double_grad(x):
+    return DoubleGrad.apply(x)
+
+
+# ==============================================================================
+#                          dense kernel matrices
+# ==============================================================================
+
+
+def gaussian_kernel(x, y, blur=0.05, **kwargs):
+    return (-squared_distances(x / blur, y / blur) / 2).exp()
+
+
+def laplacian_kernel(x, y, blur=0.05, **kwargs):
+    return (-distances(x / blur, y / blur)).exp()
+
+
+def energy_kernel(x, y, blur=None, **kwargs):
+    return -distances(x, y)
+
+
+kernel_routines = {
+    "gaussian": gaussian_kernel,
+    "laplacian": laplacian_kernel,
+    "energy": energy_kernel,
+}
+
+
+class _LazyKernel:
+    """Stand-in for the KeOps LazyTensor the reference builds at ``:62-82``: supports ``K @ v`` and ``K.t()``."""
+
+    def __init__(self, name, x, y, blur, ranges=None):
+        self.name, self.x, self.y, self.blur, self.ranges = name, x, y, blur, ranges
+
+    def __matmul__(self, v):  # v: (..., M, 1)
+        return hip.kernel_conv(self.name, self.x, self.y, v.squeeze(-1), self.blur, self.ranges).unsqueeze(-1)
+
+    def t(self):
+        return _LazyKernel(self.name, self.y, self.x, self.blur, None if self.ranges is None else self.ranges.t())
+
+
+def kernel_loss(
+    α, x, β, y, blur=0.05, kernel=None, name=None, potentials=False, use_keops=False,
+    ranges_xx=None, ranges_yy=None, ranges_xy=None, **kwargs,
+):
+    """Kernel norm or its potentials (``:92-146``).  ``use_keops=True`` selects the matrix-free HIP path
+    (the keyword keeps the reference's name; no KeOps is involved)."""
+    if use_keops:
+        if kernel is not None:
+            raise NotImplementedError(
+                "geomloss_amd: custom 'kernel' functions need dense matrices; use backend='tensorized'."
+            )
+        if name not in kernel_routines:
+            raise KeyError(name)
+        K_xx = _LazyKernel(name, double_grad(x), x.detach(), blur, ranges_xx)
+        K_yy = _LazyKernel(name, double_grad(y), y.detach(), blur, ranges_yy)
+        K_xy = _LazyKernel(name, x, y, blur, ranges_xy)
+    else:
+        if kernel is None:
+            kernel = kernel_routines[name]
+        K_xx = kernel(double_grad(x), x.detach(), blur=blur)
+        K_yy = kernel(double_grad(y), y.detach(), blur=blur)
+        K_xy = kernel(x, y, blur=blur)
+
+    a_x = (K_xx @ α.detach().unsqueeze(-1)).squeeze(-1)
+    b_y = (K_yy @ β.detach().unsqueeze(-1)).squeeze(-1)
+    b_x = (K_xy @ β.unsqueeze(-1)).squeeze(-1)
+
+    if potentials:
+        Kt = K_xy.t() if use_keops else K_xy.transpose(-1, -2)
+        a_y = (Kt @ α.unsqueeze(-1)).squeeze(-1)
+        return a_x - b_x, b_y - a_y
+
+    batch = x.dim() > 2
+    return (
+        0.5 * scal(double_grad(α), a_x, batch=batch)
+        + 0.5 * scal(double_grad(β), b_y, batch=batch)
+        - scal(α, b_x, batch=batch)
+    )
+
+
+kernel_tensorized = partial(kernel_loss, use_keops=False)
+kernel_online = partial(kernel_loss, use_keops=True)
+
+
+def max_diameter(x, y):
+    mins = torch.minimum(x.min(dim=0)[0], y.min(dim=0)[0])
+    maxs = torch.maximum(x.max(dim=0)[0], y.max(dim=0)[0])
+    return (maxs - mins).norm().item()
+
+
+def kernel_multiscale(
+    α, x, β, y, blur=0.05, kernel=None, name=None, truncate=5, diameter=None, cluster_scale=None,
+    potentials=False, verbose=False, **kwargs,
+):
+    """Block-sparse kernel norm: cluster pairs farther apart than (truncate + cell diameter) blurs are skipped (``:177-271``).
+
+    Works on single, un-batched measures.  As in the reference, the clouds are centred and sorted by
+    cluster, and returned potentials follow the sorted order.
+    """
+    if truncate is None or name == "energy":
+        return kernel_online(
+            α.unsqueeze(0), x.unsqueeze(0), β.unsqueeze(0), y.unsqueeze(0),
+            blur=blur, kernel=kernel, truncate=truncate, name=name, potentials=potentials, **kwargs,
+        )
+
+    # centre and rescale: truncation thresholds are expressed in units of blur
+    center = (x.mean(-2, keepdim=True) + y.mean(-2, keepdim=True)) / 2
+    x, y = x - center, y - center
+    x_, y_ = x / blur, y / blur
+    D = x.shape[-1]
+
+    if cluster_scale is None:
+        diameter = max_diameter(x_.view(-1, D), y_.view(-1, D)) if diameter is None else diameter / blur
+        cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
+    cell_diameter = cluster_scale * np.sqrt(D)
+
+    x_lab = grid_cluster(x_, cluster_scale)
+    y_lab = grid_cluster(y_, cluster_scale)
+    ranges_x, x_c, _ = cluster_ranges_centroids(x_, x_lab, weights=α)
+    ranges_y, y_c, _ = cluster_ranges_centroids(y_, y_lab, weights=β)
+
+    if verbose:
+        print("{}x{} clusters, computed at scale = {:2.3f}".format(len(x_c), len(y_c), cluster_scale))
+
+    (α, x), x_lab = sort_clusters((α, x), x_lab)
+    (β, y), y_lab = sort_clusters((β, y), y_lab)
+
+    with torch.no_grad():
+        reach2 = (truncate + cell_diameter) ** 2
+        ranges_xx = from_matrix(ranges_x, ranges_x, squared_distances(x_c, x_c) <= reach2)
+        ranges_yy = from_matrix(ranges_y, ranges_y, squared_distances(y_c, y_c) <= reach2)
+        ranges_xy = from_matrix(ranges_x, ranges_y, squared_distances(x_c, y_c) <= reach2)
+
+    return kernel_loss(
+        α, x, β, y, blur=blur, kernel=kernel, name=name, potentials=potentials, use_keops=True,
+        ranges_xx=ranges_xx, ranges_yy=ranges_yy, ranges_xy=ranges_xy,
+    )

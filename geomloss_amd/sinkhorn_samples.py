@@ -1,0 +1,238 @@
+"""Sinkhorn divergences between sampled measures: the three drivers behind ``SamplesLoss("sinkhorn")``.
+
+Mirror of the reference's ``_legacy/sinkhorn_samples.py`` (same function names and arguments):
+
+* ``sinkhorn_tensorized``  (``:74-221``)  dense (B,N,M) cost matrices.  CPU tensors: plain PyTorch
+  (this is the reference algorithm, BASELINE config 1).  GPU tensors: the row-wise soft-min is the
+  HIP kernel ``glhip_softmin_dense_fwd``.
+* ``sinkhorn_online``      (``:349-424``) costs recomputed on the fly from the points — HIP only.
+* ``sinkhorn_multiscale``  (``:547-681``) two-scale scheme with voxel clusters and kernel
+  truncation — HIP only, block-sparse kernels.
+
+The Sinkhorn loop itself lives in :mod:`geomloss_amd.sinkhorn_divergence`; the kernels are reached
+through :mod:`geomloss_amd.hip`.
+"""
+
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import hip
+from .cluster import cluster_ranges_centroids, from_matrix, grid_cluster, swap_axes
+from .sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
+from .utils import distances, squared_distances
+
+# ==============================================================================
+#                          backend == "tensorized"
+# ==============================================================================
+
+cost_routines = {
+    1: (lambda x, y: distances(x, y)),
+    2: (lambda x, y: squared_distances(x, y) / 2),
+}
+
+
+def softmin_tensorized(eps, C_xy, h_y):
+    """``-eps * logsumexp_j(h_j - C_ij / eps)`` for a dense (B,N,M) cost matrix (``:32-71``)."""
+    B = C_xy.shape[0]
+    if C_xy.is_cuda:
+        return hip.softmin_dense(eps, C_xy, h_y.view(B, -1)).to(C_xy.dtype)
+    return -eps * (h_y.view(B, 1, -1) - C_xy / eps).logsumexp(2).view(B, -1)
+
+
+def sinkhorn_tensorized(
+    a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, cost=None, debias=True,
+    potentials=False, **kwargs,
+):
+    """Sinkhorn divergence on explicit cost matrices; a (B,N), x (B,N,D), b (B,M), y (B,M,D)."""
+    if cost is None:
+        cost = cost_routines[p]
+
+    # right-hand sides are detached: gradients flow through the first argument of each cost only
+    C_xy = cost(x, y.detach())
+    C_yx = cost(y, x.detach())
+    C_xx = cost(x, x.detach()) if debias else None
+    C_yy = cost(y, y.detach()) if debias else None
+
+    diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+
+    f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
+        softmin_tensorized, log_weights(a), log_weights(b), C_xx, C_yy, C_xy, C_yx, eps_list, rho, debias=debias
+    )
+    return sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, batch=True, debias=debias, potentials=potentials)
+
+
+# ==============================================================================
+#                          backend == "online"
+# ==============================================================================
+
+# The reference describes the ground cost of its KeOps backends with formula strings; the HIP kernels
+# implement exactly these two.
+cost_formulas = {
+    1: "Norm2(X-Y)",
+    2: "(SqDist(X,Y) / IntCst(2))",
+}
+
+
+def _exponent_of(cost_formula):
+    """Maps a cost formula of the reference's online / multiscale API to the kernel's ``p``."""
+    for p, formula in cost_formulas.items():
+        if isinstance(cost_formula, str) and cost_formula.replace(" ", "") == formula.replace(" ", ""):
+            return p
+    raise NotImplementedError(
+        "geomloss_amd: the HIP backends implement the cost formulas "
+        f"{list(cost_formulas.values())} (p = 1, 2); got {cost_formula!r}. "
+        "Arbitrary cost functions are available with backend='tensorized'."
+    )
+
+
+def softmin_online(eps, C_xy, h_y, p=2):
+    """Soft-C-transform on implicit costs (``:337-346`` and ``:229-290``): C_xy = (x, y), batched or not."""
+    x, y = C_xy
+    out = hip.softmin(eps, x, y, h_y, p=p)
+    return out if x.dim() > 2 else out.view(1, -1)
+
+
+def sinkhorn_online(
+    a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, cost=None, debias=True,
+    potentials=False, **kwargs,
+):
+    """Sinkhorn divergence with O(N+M) memory; a (B,N), x (B,N,D), b (B,M), y (B,M,D) on a GPU."""
+    B = x.shape[0]
+    if cost is not None:
+        if B > 1:
+            raise ValueError("Custom cost functions are not yet supported with batches." "")
+        p = _exponent_of(cost)
+    if B == 1:  # like the reference, the single-problem path works on (N,D) clouds
+        x, y = x.squeeze(0), y.squeeze(0)
+    softmin = partial(softmin_online, p=p)
+
+    C_xx, C_yy = ((x, x.detach()), (y, y.detach())) if debias else (None, None)
+    C_xy, C_yx = ((x, y.detach()), (y, x.detach()))
+
+    diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+
+    f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
+        softmin, log_weights(a), log_weights(b), C_xx, C_yy, C_xy, C_yx, eps_list, rho, debias=debias
+    )
+    return sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, batch=True, debias=debias, potentials=potentials)
+
+
+# ==============================================================================
+#                          backend == "multiscale"
+# ==============================================================================
+
+
+def softmin_multiscale(eps, C_xy, f_y, p=2):
+    """Block-sparse soft-C-transform (``:445-450``): C_xy = (x, y, ranges_x, ranges_y, ranges_xy)."""
+    x, y, ranges_x, ranges_y, ranges_xy = C_xy
+    return hip.softmin(eps, x, y, f_y.view(-1), p=p, ranges=ranges_xy)
+
+
+def clusterize(a, x, scale=None, labels=None):
+    """Voxel-grid clustering of a weighted cloud (``:453-490``).
+
+    Returns ``[a_c, a], [x_c, x], [ranges_x], perm``: cluster weights / centroids, the cloud re-ordered
+    so that cluster k is ``x[ranges_x[k,0]:ranges_x[k,1]]``, and the permutation that was applied.
+    """
+    if labels is None and scale is None:
+        return [a], [x], []
+    x_lab = grid_cluster(x, scale) if labels is None else labels
+    ranges_x, x_c, a_c = cluster_ranges_centroids(x, x_lab, weights=a)
+    _, perm = torch.sort(x_lab.view(-1))
+    return [a_c, a[perm]], [x_c, x[perm]], [ranges_x], perm
+
+
+def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False):
+    """Keeps the fine blocks whose coarse dual slack allows mass: f_i + g_j > C_ij - truncate * eps (``:493-530``)."""
+    if truncate is None:
+        return C_xy_, C_yx_
+    x, yd, ranges_x, ranges_y, _ = C_xy
+    y, xd, _, _, _ = C_yx
+    x_, yd_, ranges_x_, ranges_y_, _ = C_xy_
+    y_, xd_, _, _, _ = C_yx_
+    with torch.no_grad():
+        C = cost(x, y)
+        keep = f_ba.view(-1, 1) + g_ab.view(1, -1) > C - truncate * eps
+        ranges_xy_ = from_matrix(ranges_x, ranges_y, keep)
+        if verbose:
+            ks, Cs = keep.sum(), C.shape[0] * C.shape[1]
+            print("Keep {}/{} = {:2.1f}% of the coarse cost matrix.".format(ks, Cs, 100 * float(ks) / Cs))
+    return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
+
+
+def extrapolate_samples(f_ba, g_ab, eps, damping, C_xy, b_log, C_xy_, softmin=None):
+    """Coarse-to-fine update of a potential: one soft-min of the fine points against the coarse measure (``:533-544``)."""
+    yd = C_xy[1]  # coarse source points
+    x_ = C_xy_[0]  # fine target points
+    return damping * softmin(eps, (x_, yd, None, None, None), (b_log + g_ab / eps).detach())
+
+
+def sinkhorn_multiscale(
+    a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5, cost=None,
+    cluster_scale=None, debias=True, potentials=False, labels_x=None, labels_y=None, verbose=False, **kwargs,
+):
+    """Two-scale Sinkhorn divergence; a (N,), x (N,D), b (M,), y (M,D) on a GPU (``:547-681``)."""
+    N, D = x.shape
+    if cost is None:
+        cost = cost_formulas[p], cost_routines[p]
+    cost_formula, cost_routine = cost[0], cost[1]
+    p_kernel = _exponent_of(cost_formula)
+    softmin = partial(softmin_multiscale, p=p_kernel)
+    extrapolate = partial(extrapolate_samples, softmin=softmin)
+
+    diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+
+    # voxel size: about 2000 cells over the bounding box
+    if cluster_scale is None:
+        cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
+    [a_c, a], [x_c, x], [ranges_x], perm_x = clusterize(a, x, scale=cluster_scale, labels=labels_x)
+    [b_c, b], [y_c, y], [ranges_y], perm_y = clusterize(b, y, scale=cluster_scale, labels=labels_y)
+
+    # Switch to the fine clouds once the blur radius drops below the voxel size.
+    # N.B.: like the reference (``:593-597``) the search variable is named `eps`, so the temperature
+    # handed to sinkhorn_cost below is the one at which the search stopped.  The balanced formulas do
+    # not use it.
+    jumps = [len(eps_list) - 1]
+    for i, eps in enumerate(eps_list[2:]):
+        if cluster_scale**p > eps:
+            jumps = [i + 1]
+            break
+
+    if verbose:
+        print("{}x{} clusters, computed at scale = {:2.3f}".format(len(x_c), len(y_c), cluster_scale))
+        print("Successive scales : ", ", ".join(["{:.3f}".format(x ** (1 / p)) for x in eps_list]))
+        if jumps[0] >= len(eps_list) - 1:
+            print("Extrapolate from coarse to fine after the last iteration.")
+        else:
+            print(
+                "Jump from coarse to fine between indices {} (σ={:2.3f}) and {} (σ={:2.3f}).".format(
+                    jumps[0], eps_list[jumps[0]] ** (1 / p), jumps[0] + 1, eps_list[jumps[0] + 1] ** (1 / p)
+                )
+            )
+
+    a_logs = [log_weights(a_c), log_weights(a)]
+    b_logs = [log_weights(b_c), log_weights(b)]
+    if debias:
+        C_xxs = [(x_c, x_c.detach(), ranges_x, ranges_x, None), (x, x.detach(), None, None, None)]
+        C_yys = [(y_c, y_c.detach(), ranges_y, ranges_y, None), (y, y.detach(), None, None, None)]
+    else:
+        C_xxs = C_yys = None
+    C_xys = [(x_c, y_c.detach(), ranges_x, ranges_y, None), (x, y.detach(), None, None, None)]
+    C_yxs = [(y_c, x_c.detach(), ranges_y, ranges_x, None), (y, x.detach(), None, None, None)]
+
+    f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
+        softmin, a_logs, b_logs, C_xxs, C_yys, C_xys, C_yxs, eps_list, rho,
+        jumps=jumps, cost=cost_routine, kernel_truncation=partial(kernel_truncation, verbose=verbose),
+        truncate=truncate, extrapolate=extrapolate, debias=debias,
+    )
+
+    cost = sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
+
+    if potentials:  # undo the cluster sort
+        F_x, G_y = cost
+        f_x, g_y = F_x.clone(), G_y.clone()
+        f_x[perm_x], g_y[perm_y] = F_x, G_y
+        return f_x, g_y
+    return cost

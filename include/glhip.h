@@ -1,0 +1,149 @@
+/*
+ * glhip.h — C-ABI of libgeomloss_hip.so: the MI355X (gfx950) map-reduce kernels
+ * behind geomloss's `SamplesLoss(backend="online"|"multiscale")`.
+ *
+ * The reference (jeanfeydy/geomloss 0.3.1) has no FFI of its own for this path:
+ * it calls the third-party, un-vendored `pykeops` package, which JIT-compiles
+ * one CUDA map-reduce per formula.  Each entry point below replaces one such
+ * pykeops call site; the call site is cited next to it (paths relative to
+ * /root/reference/src/geomloss/_legacy/).
+ *
+ * Conventions (all entry points)
+ *   - plain C: raw device pointers, ints, floats; no C++ / torch types.
+ *   - the caller owns every buffer; the library never allocates, frees or
+ *     retains device memory.  All arrays are contiguous, row-major.
+ *   - point clouds are (B, N, D) "array of structs", exactly as torch stores
+ *     a contiguous (B,N,D) tensor; `in_dtype` selects their element type
+ *     (GLHIP_F32 | GLHIP_BF16).  Dual vectors, weights, outputs and all
+ *     accumulation are fp32.
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) on the current device; nothing synchronises.
+ *   - return value: 0 on success, a negative GLHIP_E* code otherwise; the
+ *     message is available (thread-local) from glhip_last_error().
+ *   - NaN/Inf propagate, they are not trapped (reference behaviour).
+ *
+ * Block-sparse reductions ("ranges", KeOps convention, int32 device arrays;
+ * built at sinkhorn_samples.py:515 / kernel_samples.py:254-256 by
+ * pykeops.torch.cluster.from_matrix):
+ *   ranges_i    (n_ranges, 2)  row blocks [start, end) — rows outside every
+ *                              block are left untouched in the output
+ *   slices_i    (n_ranges,)    CSR end offsets into redranges_j; block k owns
+ *                              redranges_j[slices_i[k-1] : slices_i[k]] (slices_i[-1] = 0)
+ *   redranges_j (nnz, 2)       column intervals [start, end) to reduce over
+ *   n_ranges == 0 (pointers may be NULL) means a dense reduction over all j.
+ *   Block-sparse mode requires B == 1 (as in the reference: samples_loss.py:249-257).
+ *   A row block with no column interval reduces over the empty set.
+ */
+#ifndef GLHIP_H
+#define GLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLHIP_VERSION 100 /* 0.1.0 */
+
+/* element type of the point clouds x, y */
+#define GLHIP_F32 0
+#define GLHIP_BF16 1
+
+/* kernel-convolution kinds (kernel_samples.py:62-82) */
+#define GLHIP_GAUSSIAN 0  /* k = exp(-|x-y|^2 / (2 blur^2))  kernel_samples.py:62-68 */
+#define GLHIP_LAPLACIAN 1 /* k = exp(-|x-y| / blur)          kernel_samples.py:71-77 */
+#define GLHIP_ENERGY 2    /* k = -|x-y|  (blur ignored)      kernel_samples.py:80-82 */
+
+/* flags (bitmask) */
+#define GLHIP_FLAG_DIRECT 1 /* p=2 softmin: evaluate |x-y|^2 as sum (x_d-y_d)^2 (KeOps' SqDist)
+                               instead of the per-workgroup-centred expansion. Slower, tighter. */
+
+/* error codes */
+#define GLHIP_OK 0
+#define GLHIP_EINVAL (-1)       /* bad argument (NULL pointer, negative size, bad enum) */
+#define GLHIP_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define GLHIP_ELAUNCH (-3)      /* hipGetLastError() after the launch was not hipSuccess */
+
+int glhip_version(void);
+const char* glhip_last_error(void);
+
+/*
+ * Soft-C-transform  out[b,i] = -eps * log sum_j exp( h[b,j] - C(x[b,i], y[b,j]) / eps ),
+ * C = |x-y|^2 / 2 (p == 2) or |x-y| (p == 1).
+ *
+ * Replaces: pykeops generic_logsumexp("(B - (P * cost))", ...) built by
+ *   lse_genred  sinkhorn_samples.py:322-334  and  keops_lse  :432-442,
+ *   as called by softmin_online :337-346, softmin_online_lazytensor :229-290 (B > 1)
+ *   and softmin_multiscale :445-450 (ranges != NULL).
+ * Same function as softmin_tensorized :32-71 on C = cost_routines[p](x, y) :26-29.
+ *
+ *   x (B,N,D)  y (B,M,D)  h (B,M) fp32  out (B,N) fp32
+ */
+int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
+                      int B, int N, int M, int D, float eps, int p, int in_dtype,
+                      const int32_t* ranges_i, const int32_t* slices_i,
+                      const int32_t* redranges_j, int n_ranges,
+                      int flags, void* stream);
+
+/*
+ * Gradient of the above with respect to x (the only differentiable argument on the
+ * reference's path: y and h are detached at sinkhorn_samples.py:392-393,628-651 and
+ * sinkhorn_divergence.py:616-623):
+ *   grad_x[b,i,:] = grad_out[b,i] * sum_j P_ij * dC/dx(x_i, y_j),
+ *   P_ij = exp( h_j - C_ij/eps + out_i/eps )   (rows of P sum to 1; we renormalise by the
+ *   recomputed row sum, as autograd's logsumexp backward does).
+ * Replaces: the symbolic KeOps `Grad` of the generic_logsumexp above.
+ *   out = the saved forward result (B,N);  grad_out (B,N) fp32;  grad_x (B,N,D) fp32.
+ */
+int glhip_softmin_bwd_x(const void* x, const void* y, const float* h,
+                        const float* out, const float* grad_out, float* grad_x,
+                        int B, int N, int M, int D, float eps, int p, int in_dtype,
+                        const int32_t* ranges_i, const int32_t* slices_i,
+                        const int32_t* redranges_j, int n_ranges,
+                        int flags, void* stream);
+
+/*
+ * Kernel-matrix × vector product  out[b,i] = sum_j k(x[b,i], y[b,j]) * v[b,j].
+ *
+ * Replaces: `K @ v` on a KeOps LazyTensor K (kernel_samples.py:128,130,132,136-137)
+ *   with K from gaussian_kernel / laplacian_kernel / energy_kernel (:62-82),
+ *   optionally block-sparse (K.ranges = ranges, :66-67,75-76).
+ *   The transposed product K^T @ a (:135-137) is the same call with x and y swapped.
+ *
+ *   v (B,M) fp32, out (B,N) fp32.
+ */
+int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v, float* out,
+                          int B, int N, int M, int D, float blur, int in_dtype,
+                          const int32_t* ranges_i, const int32_t* slices_i,
+                          const int32_t* redranges_j, int n_ranges,
+                          int flags, void* stream);
+
+/*
+ * Gradient of sum_i g_i * out_i (out from glhip_kernel_conv_fwd) with respect to x:
+ *   grad_x[b,i,:] = g[b,i] * sum_j v[b,j] * dk/dx(x_i, y_j),
+ *   with the convention d|z|/dz = 0 at z = 0 (what KeOps' Norm2 gradient returns and what the
+ *   clamp at utils.py:61 yields in the dense code).
+ * The gradient with respect to y is the same call with (x,g) and (y,v) swapped; the gradient
+ * with respect to v is glhip_kernel_conv_fwd with x and y swapped and v := g.
+ * Replaces: KeOps autograd of the reductions at kernel_samples.py:128-137.
+ */
+int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float* v,
+                            const float* g, float* grad_x,
+                            int B, int N, int M, int D, float blur, int in_dtype,
+                            const int32_t* ranges_i, const int32_t* slices_i,
+                            const int32_t* redranges_j, int n_ranges,
+                            int flags, void* stream);
+
+/*
+ * Row-wise soft-min of an explicit (B,N,M) fp32 cost matrix:
+ *   out[b,i] = -eps * log sum_j exp( h[b,j] - C[b,i,j] / eps ).
+ * Replaces: softmin_tensorized sinkhorn_samples.py:32-71 for CUDA tensors
+ *   (the `backend="tensorized"` path, including user-supplied `cost` callables).
+ */
+int glhip_softmin_dense_fwd(const float* C, const float* h, float* out,
+                            int B, int N, int M, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLHIP_H */
