@@ -93,6 +93,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.t = (p == 1) ? s2 : std::sqrt(0.5f * s2);
         prm.inv_t = 1.0f / prm.t;
         prm.out_scale = out_scale;
+        prm.clamp2 = 1e-8f * prm.t * prm.t;
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
@@ -111,6 +112,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.dscale = (p == 1) ? s2 : 0.5f * s2;
         prm.out_scale = out_scale;
         prm.gscale = 1.f;
+        prm.clamp2 = 1e-8f;
         const bool sp = n_ranges > 0;
         dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
 #define GL_LAUNCH(MODE, SP) \
@@ -152,14 +154,17 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
         if (kind == GLHIP_GAUSSIAN) {
             prm.t = std::sqrt(0.5f * kLog2e) / blur;
             prm.gscale = -1.0f / (prm.t * blur * blur);
+            prm.clamp2 = 0.f;
             launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
         } else if (kind == GLHIP_LAPLACIAN) {
             prm.t = kLog2e / blur;
             prm.gscale = -1.0f / blur;
+            prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
             launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
         } else {
             prm.t = 1.0f;
             prm.gscale = -1.0f;
+            prm.clamp2 = 1e-8f;
             launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
         }
     } else {
@@ -175,6 +180,7 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
         prm.g = g;
         prm.gx = gx;
         prm.out_scale = 1.f;
+        prm.clamp2 = 1e-8f;
         const bool sp = n_ranges > 0;
         dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
 #define GL_LAUNCH(MODE, SP) \
@@ -186,6 +192,7 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
         } else if (kind == GLHIP_LAPLACIAN) {
             prm.dscale = kLog2e / blur;
             prm.gscale = -1.0f / blur;
+            prm.clamp2 = 1e-8f * blur * blur;
             if (sp) GL_LAUNCH(GM_LAPLACE, true); else GL_LAUNCH(GM_LAPLACE, false);
         } else {
             prm.dscale = 1.f;

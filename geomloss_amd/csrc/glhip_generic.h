@@ -29,16 +29,17 @@ struct GenericParams {
     float dscale;       // factor on d2 (p=2 / gaussian) or on sqrt(d2) (p=1 / laplacian), base-2 units
     float out_scale;    // softmin: -eps ln2
     float gscale;       // kernel bwd: factor on the accumulated direction sum
+    float clamp2;       // floor on squared distances under a square root (1e-8, utils.py:61)
 };
 
 template <int MODE>
-__device__ __forceinline__ float generic_value(float d2, float sj, float dscale) {
+__device__ __forceinline__ float generic_value(float d2, float sj, float dscale, float clamp2) {
     // softmin: exponent u_ij (base 2);  kernels: k_ij (unweighted)
     if (MODE == GM_SOFTMIN_P2) return __builtin_fmaf(-d2, dscale, sj);
-    if (MODE == GM_SOFTMIN_P1) return __builtin_fmaf(-fast_sqrt(d2), dscale, sj);
+    if (MODE == GM_SOFTMIN_P1) return __builtin_fmaf(-fast_sqrt(fmaxf(d2, clamp2)), dscale, sj);
     if (MODE == GM_GAUSS) return fast_exp2(-d2 * dscale);
-    if (MODE == GM_LAPLACE) return fast_exp2(-fast_sqrt(d2) * dscale);
-    return -fast_sqrt(d2);
+    if (MODE == GM_LAPLACE) return fast_exp2(-fast_sqrt(fmaxf(d2, clamp2)) * dscale);
+    return -fast_sqrt(fmaxf(d2, clamp2));
 }
 
 template <int MODE, bool BWD, bool SPARSE, typename T>
@@ -122,7 +123,7 @@ generic_kernel(GenericParams<T> p, Ranges rg, int N, int M, int D) {
                     if (SOFTMIN) {
                         float u[kJT];
 #pragma unroll
-                        for (int jj = 0; jj < kJT; ++jj) u[jj] = generic_value<MODE>(d2[jj], sj[jj], p.dscale);
+                        for (int jj = 0; jj < kJT; ++jj) u[jj] = generic_value<MODE>(d2[jj], sj[jj], p.dscale, p.clamp2);
                         float cm = u[0];
 #pragma unroll
                         for (int jj = 1; jj < kJT; ++jj) cm = fmaxf(cm, u[jj]);
@@ -134,22 +135,22 @@ generic_kernel(GenericParams<T> p, Ranges rg, int N, int M, int D) {
                     } else {
 #pragma unroll
                         for (int jj = 0; jj < kJT; ++jj)
-                            accv = __builtin_fmaf(generic_value<MODE>(d2[jj], 0.f, p.dscale), sj[jj], accv);
+                            accv = __builtin_fmaf(generic_value<MODE>(d2[jj], 0.f, p.dscale, p.clamp2), sj[jj], accv);
                     }
                 } else {
                     // direction weights w_j, then a second sweep over the feature chunks
                     float w[kJT];
 #pragma unroll
                     for (int jj = 0; jj < kJT; ++jj) {
-                        const float rs = (d2[jj] > 0.f) ? fast_rsq(d2[jj]) : 0.f;
+                        const float rs = (d2[jj] > p.clamp2) ? fast_rsq(d2[jj]) : 0.f;
                         if (SOFTMIN) {
-                            const float pij = fast_exp2(generic_value<MODE>(d2[jj], sj[jj], p.dscale) - lse2);
+                            const float pij = fast_exp2(generic_value<MODE>(d2[jj], sj[jj], p.dscale, p.clamp2) - lse2);
                             ssum += pij;
                             w[jj] = (MODE == GM_SOFTMIN_P2) ? pij : pij * rs;
                         } else if (MODE == GM_GAUSS) {
-                            w[jj] = sj[jj] * generic_value<MODE>(d2[jj], 0.f, p.dscale);
+                            w[jj] = sj[jj] * generic_value<MODE>(d2[jj], 0.f, p.dscale, p.clamp2);
                         } else if (MODE == GM_LAPLACE) {
-                            w[jj] = sj[jj] * rs * generic_value<MODE>(d2[jj], 0.f, p.dscale);
+                            w[jj] = sj[jj] * rs * generic_value<MODE>(d2[jj], 0.f, p.dscale, p.clamp2);
                         } else {
                             w[jj] = sj[jj] * rs;
                         }

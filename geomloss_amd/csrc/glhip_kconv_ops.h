@@ -9,6 +9,7 @@
 //   gaussian : t = sqrt(log2(e)/2) / blur,  k = 2^(-|xs-ys|^2)
 //   laplacian: t = log2(e) / blur,          k = 2^(-|xs-ys|)
 //   energy   : t = 1,                       k = -|xs-ys|
+// with |.| floored at 1e-4 t, the clamp of the reference's dense `distances` (utils.py:61).
 // LDS record: { ys_0 .. ys_{D-1}, v_j }.
 #pragma once
 
@@ -26,13 +27,14 @@ struct ConvParams {
     float* gx;         // bwd: (B,N,D)
     float t;           // coordinate pre-scale
     float gscale;      // bwd: factor applied to the accumulated direction sum
+    float clamp2;      // laplacian / energy: floor on the scaled squared distance, 1e-8 * t^2 (utils.py:61)
 };
 
 template <int KIND>
-__device__ __forceinline__ float radial_kernel(float d2) {
+__device__ __forceinline__ float radial_kernel(float d2, float clamp2) {
     if (KIND == GLHIP_GAUSSIAN) return fast_exp2(-d2);
-    if (KIND == GLHIP_LAPLACIAN) return fast_exp2(-fast_sqrt(d2));
-    return -fast_sqrt(d2);
+    if (KIND == GLHIP_LAPLACIAN) return fast_exp2(-fast_sqrt(fmaxf(d2, clamp2)));
+    return -fast_sqrt(fmaxf(d2, clamp2));
 }
 
 template <int KIND, int D_, int R, typename T, bool BWD>
@@ -43,6 +45,7 @@ struct ConvOp {
     struct RowState {
         float a[R][D_];
         float acc[R][BWD ? D_ : 1];
+        float clamp2;
     };
 
     static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
@@ -51,6 +54,7 @@ struct ConvOp {
 
     static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
                                                      int tid, const float (&c)[D_], RowState& st) {
+        st.clamp2 = p.clamp2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = min(row0 + r * kBlock + tid, row_end - 1);
@@ -100,14 +104,14 @@ struct ConvOp {
                 }
                 const float vj = rec_tail<D_>(rc[c]);
                 if (!BWD) {
-                    st.acc[r][0] = __builtin_fmaf(radial_kernel<KIND>(d2), vj, st.acc[r][0]);
+                    st.acc[r][0] = __builtin_fmaf(radial_kernel<KIND>(d2, st.clamp2), vj, st.acc[r][0]);
                 } else {
                     // weight of the direction (xs - ys):  gaussian k ; laplacian k/|.| ; energy 1/|.|
                     float w;
                     if (KIND == GLHIP_GAUSSIAN) {
                         w = vj * fast_exp2(-d2);
                     } else {
-                        const float rs = (d2 > 0.f) ? fast_rsq(d2) : 0.f;
+                        const float rs = (d2 > st.clamp2) ? fast_rsq(d2) : 0.f;
                         w = (KIND == GLHIP_LAPLACIAN) ? vj * rs * fast_exp2(-d2 * rs) : vj * rs;
                     }
 #pragma unroll

@@ -12,7 +12,8 @@
 //     r_i is constant along the row and is added after the reduction.
 //   DIRECT (p = 1, or p = 2 with GLHIP_FLAG_DIRECT): coordinates pre-scaled by t,
 //       p = 2: t = sqrt(s2/2), u_ij = H_j - sum_d (xs_d - ys_d)^2
-//       p = 1: t = s2,         u_ij = H_j - sqrt( sum_d (xs_d - ys_d)^2 )      (KeOps' Norm2, no clamp)
+//       p = 1: t = s2,         u_ij = H_j - sqrt( max( sum_d (xs_d - ys_d)^2, 1e-8 t^2 ) )
+//              (the floor is the clamp of the reference's dense cost, utils.py:61)
 //
 // The running maximum is exact (updated every kChunk columns), so no threshold / rescale branch exists.
 #pragma once
@@ -34,6 +35,7 @@ struct SoftminParams {
     float t;           // coordinate pre-scale of the DIRECT form
     float inv_t;       // 1 / t
     float out_scale;   // -eps * ln(2)
+    float clamp2;      // p = 1: floor on the (scaled) squared distance, 1e-8 * t^2 (utils.py:61)
 };
 
 // ---- shared pieces ---------------------------------------------------------------------------
@@ -63,7 +65,7 @@ __device__ __forceinline__ void lse_update(float& m, float& s, const float (&u)[
 
 // u for one (row, record) pair
 template <int D, int P, bool DIRECT>
-__device__ __forceinline__ float pair_exponent(const float (&a)[D], const Rec<D>& r) {
+__device__ __forceinline__ float pair_exponent(const float (&a)[D], const Rec<D>& r, float clamp2) {
     if (!DIRECT) {
         float u = rec_tail<D>(r);
 #pragma unroll
@@ -84,7 +86,7 @@ __device__ __forceinline__ float pair_exponent(const float (&a)[D], const Rec<D>
             const float df = a[d] - r.c[d];
             d2 = __builtin_fmaf(df, df, d2);
         }
-        return rec_tail<D>(r) - fast_sqrt(d2);
+        return rec_tail<D>(r) - fast_sqrt(fmaxf(d2, clamp2));
     }
 }
 
@@ -99,6 +101,7 @@ struct SoftminFwdOp {
         float a[R][D_];   // scaled, centred row coordinates
         float r[R];       // row constant of the expanded form (0 for DIRECT)
         float m[R], s[R];
+        float clamp2;
     };
 
     static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
@@ -107,6 +110,7 @@ struct SoftminFwdOp {
 
     static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
                                                      int tid, const float (&c)[D_], RowState& st) {
+        st.clamp2 = p.clamp2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = min(row0 + r * kBlock + tid, row_end - 1);   // clamp: idle lanes redo a valid row
@@ -159,7 +163,7 @@ struct SoftminFwdOp {
         for (int r = 0; r < R; ++r) {
             float u[kChunk];
 #pragma unroll
-            for (int c = 0; c < kChunk; ++c) u[c] = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c]);
+            for (int c = 0; c < kChunk; ++c) u[c] = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c], st.clamp2);
             lse_update(st.m[r], st.s[r], u);
         }
     }
@@ -191,6 +195,7 @@ struct SoftminBwdOp {
         float l[R];        // LSE2_i minus the row constant r_i
         float acc[R][D_];
         float sw[R];
+        float clamp2;
     };
 
     static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
@@ -199,6 +204,7 @@ struct SoftminBwdOp {
 
     static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end,
                                                      int tid, const float (&c)[D_], RowState& st) {
+        st.clamp2 = p.clamp2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = min(row0 + r * kBlock + tid, row_end - 1);
@@ -233,7 +239,7 @@ struct SoftminBwdOp {
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int c = 0; c < kChunk; ++c) {
-                const float u = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c]);
+                const float u = pair_exponent<D_, P, DIRECT>(st.a[r], rc[c], st.clamp2);
                 const float w = fast_exp2(u - st.l[r]);
                 st.sw[r] += w;
                 if (P == 2) {
@@ -247,7 +253,7 @@ struct SoftminBwdOp {
                         df[d] = st.a[r][d] - rc[c].c[d];
                         d2 = __builtin_fmaf(df[d], df[d], d2);
                     }
-                    const float wr = (d2 > 0.f) ? w * fast_rsq(d2) : 0.f;
+                    const float wr = (d2 > st.clamp2) ? w * fast_rsq(d2) : 0.f;
 #pragma unroll
                     for (int d = 0; d < D_; ++d) st.acc[r][d] = __builtin_fmaf(wr, df[d], st.acc[r][d]);
                 }

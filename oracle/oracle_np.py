@@ -1,0 +1,441 @@
+"""CPU oracle (NumPy, float64 by default) for the hot path of geomloss's ``SamplesLoss``.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``geomloss_amd/`` imports this module; only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may.
+
+Every function restates one piece of the reference (paths relative to
+/root/reference/src/geomloss/_legacy/) and cites it.  Pinning: the reference's own test-suite
+never exercises ``SamplesLoss``; this oracle is pinned instead against outputs of the reference's
+tensorized backend generated in the build container (``tests/golden/*.npz``, produced by
+``tests/golden/make_golden.py``) — see ``tests/test_oracle_golden.py``.  The two-scale
+("multiscale") algorithm cannot be run from the reference here (it needs pykeops, which is not
+installed and not vendored): for that backend the oracle restates the algorithm of
+``sinkhorn_samples.py:453-681`` with dense masked matrices, and its clustering follows the
+documented semantics of ``pykeops.torch.cluster`` — parity of the *clustering helper* with
+pykeops itself is unpinned.
+"""
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------
+#  costs and the soft-min
+# --------------------------------------------------------------------------------------------------
+
+
+def squared_distances(x, y):
+    """|x_i - y_j|^2 for (..., N, D) x (..., M, D), by explicit differences (utils.py:26-53 computes the
+    same quantity through |x|^2 - 2x.y + |y|^2; in float64 the two agree to ~1e-15)."""
+    diff = x[..., :, None, :] - y[..., None, :, :]
+    return (diff * diff).sum(-1)
+
+
+def distances(x, y):
+    """sqrt(max(|x_i - y_j|^2, 1e-8))  — utils.py:56-61 (dense mode clamps before the root)."""
+    return np.sqrt(np.maximum(squared_distances(x, y), 1e-8))
+
+
+def cost_matrix(x, y, p=2):
+    """C(x_i, y_j) = |x_i-y_j|^2 / 2 (p=2) or |x_i-y_j| (p=1)  — cost_routines, sinkhorn_samples.py:26-29."""
+    if p == 2:
+        return squared_distances(x, y) / 2
+    if p == 1:
+        return distances(x, y)
+    raise NotImplementedError("p must be 1 or 2")
+
+
+def logsumexp(v, axis=-1):
+    m = np.max(v, axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    with np.errstate(divide="ignore"):
+        return np.log(np.exp(v - m).sum(axis=axis)) + np.squeeze(m, axis=axis)
+
+
+def softmin_dense(eps, C, h):
+    """f_i = -eps * log sum_j exp(h_j - C_ij/eps)  — softmin_tensorized, sinkhorn_samples.py:70-71.
+    C: (..., N, M), h: (..., M) -> (..., N)."""
+    return -eps * logsumexp(h[..., None, :] - C / eps, axis=-1)
+
+
+def softmin_points(eps, x, y, h, p=2, dtype=np.float64, row_block=2048):
+    """Same quantity from the points, row-blocked so that large N x M fit in memory
+    (what softmin_online computes: sinkhorn_samples.py:337-346)."""
+    x, y, h = np.asarray(x, dtype), np.asarray(y, dtype), np.asarray(h, dtype)
+    out = np.empty(x.shape[:-1], dtype)
+    N = x.shape[-2]
+    for i0 in range(0, N, row_block):
+        C = cost_matrix(x[..., i0:i0 + row_block, :], y, p)
+        out[..., i0:i0 + row_block] = softmin_dense(eps, C, h)
+    return out
+
+
+def softmin_points_grad_x(eps, x, y, h, g, p=2, dtype=np.float64, row_block=2048):
+    """d/dx of sum_i g_i f_i:  g_i sum_j P_ij dC/dx(x_i,y_j), P = softmax_j(h_j - C_ij/eps).
+    (What autograd produces through logsumexp in the tensorized code; SURVEY Appendix A.)"""
+    x, y, h, g = (np.asarray(t, dtype) for t in (x, y, h, g))
+    gx = np.empty_like(x)
+    N = x.shape[-2]
+    for i0 in range(0, N, row_block):
+        xb = x[..., i0:i0 + row_block, :]
+        C = cost_matrix(xb, y, p)
+        v = h[..., None, :] - C / eps
+        v = v - v.max(-1, keepdims=True)
+        P = np.exp(v)
+        P /= P.sum(-1, keepdims=True)
+        diff = xb[..., :, None, :] - y[..., None, :, :]
+        if p == 1:  # gradient of sqrt(clamp_min(d2, 1e-8)): zero where the clamp is active
+            n2 = (diff * diff).sum(-1, keepdims=True)
+            diff = np.where(n2 > 1e-8, diff / np.sqrt(np.where(n2 > 1e-8, n2, 1.0)), 0.0)
+        gx[..., i0:i0 + row_block, :] = g[..., i0:i0 + row_block, None] * (P[..., None] * diff).sum(-2)
+    return gx
+
+
+# --------------------------------------------------------------------------------------------------
+#  epsilon schedule and loss formulas  (sinkhorn_divergence.py)
+# --------------------------------------------------------------------------------------------------
+
+
+def dampening(eps, rho):
+    """sinkhorn_divergence.py:56-58"""
+    return 1.0 if rho is None else 1.0 / (1.0 + eps / rho)
+
+
+def log_weights(a):
+    """sinkhorn_divergence.py:61-65"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.log(a)
+    out[a <= 0] = -100000.0
+    return out
+
+
+def max_diameter(x, y):
+    """sinkhorn_divergence.py:96-112 (bounding box of the flattened batch, :156-158)"""
+    D = x.shape[-1]
+    xf, yf = x.reshape(-1, D), y.reshape(-1, D)
+    mins = np.minimum(xf.min(0), yf.min(0))
+    maxs = np.maximum(xf.max(0), yf.max(0))
+    return float(np.linalg.norm(maxs - mins))
+
+
+def epsilon_schedule(p, diameter, blur, scaling):
+    """sinkhorn_divergence.py:141-151"""
+    return ([diameter**p]
+            + [np.exp(e) for e in np.arange(p * np.log(diameter), p * np.log(blur), p * np.log(scaling))]
+            + [blur**p])
+
+
+def scaling_parameters(x, y, p, blur, reach, diameter, scaling):
+    """sinkhorn_divergence.py:154-163"""
+    if diameter is None:
+        # the reference measures the box on the tensors it is given (float32 there): do the same
+        diameter = max_diameter(x.astype(np.float32), y.astype(np.float32))
+    eps = blur**p
+    rho = None if reach is None else reach**p
+    return diameter, eps, epsilon_schedule(p, diameter, blur, scaling), rho
+
+
+def scal(a, f):
+    """utils.py:13-18, batched over leading axes"""
+    return (a * f).sum(-1)
+
+
+def sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=True, potentials=False):
+    """sinkhorn_divergence.py:171-250"""
+    if potentials:
+        return (f_ba - f_aa, g_ab - g_bb) if debias else (f_ba, g_ab)
+    if rho is None:
+        if debias:
+            return scal(a, f_ba - f_aa) + scal(b, g_ab - g_bb)
+        return scal(a, f_ba) + scal(b, g_ab)
+    w = rho + eps / 2
+    if debias:
+        return (scal(a, w * (np.exp(-f_aa / rho) - np.exp(-f_ba / rho)))
+                + scal(b, w * (np.exp(-g_bb / rho) - np.exp(-g_ab / rho))))
+    return scal(a, w * (1 - np.exp(-f_ba / rho))) + scal(b, w * (1 - np.exp(-g_ab / rho)))
+
+
+# --------------------------------------------------------------------------------------------------
+#  the Sinkhorn loop  (sinkhorn_divergence.py:258-628)
+# --------------------------------------------------------------------------------------------------
+
+
+def sinkhorn_loop(softmin, a_logs, b_logs, C_xxs, C_yys, C_xys, C_yxs, eps_list, rho, jumps=(),
+                  kernel_truncation=None, truncate=5, cost=None, extrapolate=None, debias=True):
+    """Returns (f_aa, g_bb, g_ab, f_ba) and the inputs of the last (differentiable) soft-mins.
+
+    Level lists have one entry (single scale) or two (coarse, fine).  Statement order follows
+    sinkhorn_divergence.py:434-628: init at eps_list[0] (:461-465), symmetric averaged updates
+    (:468-493), optional jump with truncation + extrapolation (:519-606), last non-averaged update
+    (:612-623)."""
+    k = 0
+    a_log, b_log = a_logs[k], b_logs[k]
+    C_xy, C_yx = C_xys[k], C_yxs[k]
+    C_xx, C_yy = (C_xxs[k], C_yys[k]) if debias else (None, None)
+
+    eps = eps_list[0]
+    lam = dampening(eps, rho)
+    g_ab = lam * softmin(eps, C_yx, a_log)
+    f_ba = lam * softmin(eps, C_xy, b_log)
+    if debias:
+        f_aa = lam * softmin(eps, C_xx, a_log)
+        g_bb = lam * softmin(eps, C_yy, b_log)
+    else:
+        f_aa = g_bb = None
+
+    last_extrapolation = True
+    for i, eps in enumerate(eps_list):
+        lam = dampening(eps, rho)
+        ft_ba = lam * softmin(eps, C_xy, b_log + g_ab / eps)
+        gt_ab = lam * softmin(eps, C_yx, a_log + f_ba / eps)
+        if debias:
+            ft_aa = lam * softmin(eps, C_xx, a_log + f_aa / eps)
+            gt_bb = lam * softmin(eps, C_yy, b_log + g_bb / eps)
+        f_ba, g_ab = 0.5 * (f_ba + ft_ba), 0.5 * (g_ab + gt_ab)
+        if debias:
+            f_aa, g_bb = 0.5 * (f_aa + ft_aa), 0.5 * (g_bb + gt_bb)
+
+        if i in jumps:
+            if i == len(eps_list) - 1:
+                C_xy_f, C_yx_f = C_xys[k + 1], C_yxs[k + 1]
+                if debias:
+                    C_xx_f, C_yy_f = C_xxs[k + 1], C_yys[k + 1]
+                last_extrapolation = False
+            else:
+                C_xy_f, C_yx_f = kernel_truncation(C_xy, C_yx, C_xys[k + 1], C_yxs[k + 1], f_ba, g_ab, eps,
+                                                   truncate=truncate, cost=cost)
+                if debias:
+                    C_xx_f, _ = kernel_truncation(C_xx, C_xx, C_xxs[k + 1], C_xxs[k + 1], f_aa, f_aa, eps,
+                                                  truncate=truncate, cost=cost)
+                    C_yy_f, _ = kernel_truncation(C_yy, C_yy, C_yys[k + 1], C_yys[k + 1], g_bb, g_bb, eps,
+                                                  truncate=truncate, cost=cost)
+            f_ba, g_ab = (extrapolate(f_ba, g_ab, eps, lam, C_xy, b_log, C_xy_f),
+                          extrapolate(g_ab, f_ba, eps, lam, C_yx, a_log, C_yx_f))
+            if debias:
+                f_aa = extrapolate(f_aa, f_aa, eps, lam, C_xx, a_log, C_xx_f)
+                g_bb = extrapolate(g_bb, g_bb, eps, lam, C_yy, b_log, C_yy_f)
+            k += 1
+            a_log, b_log = a_logs[k], b_logs[k]
+            C_xy, C_yx = C_xy_f, C_yx_f
+            if debias:
+                C_xx, C_yy = C_xx_f, C_yy_f
+
+    last = dict(eps=eps, lam=lam, C_xy=C_xy, C_yx=C_yx, C_xx=C_xx, C_yy=C_yy, a_log=a_log, b_log=b_log)
+    if last_extrapolation:
+        last["h_ba"], last["h_ab"] = b_log + g_ab / eps, a_log + f_ba / eps
+        if debias:
+            last["h_aa"], last["h_bb"] = a_log + f_aa / eps, b_log + g_bb / eps
+        f_ba, g_ab = lam * softmin(eps, C_xy, last["h_ba"]), lam * softmin(eps, C_yx, last["h_ab"])
+        if debias:
+            f_aa, g_bb = lam * softmin(eps, C_xx, last["h_aa"]), lam * softmin(eps, C_yy, last["h_bb"])
+    return (f_aa, g_bb, g_ab, f_ba), last
+
+
+# --------------------------------------------------------------------------------------------------
+#  tensorized Sinkhorn  (sinkhorn_samples.py:74-221)  = the parity target of BASELINE.json
+# --------------------------------------------------------------------------------------------------
+
+
+def _uniform(n, lead, dtype):
+    return np.full(lead + (n,), 1.0 / n, dtype)
+
+
+def sinkhorn_tensorized(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, debias=True,
+                        potentials=False, return_internals=False):
+    """a (...,N), x (...,N,D), b (...,M), y (...,M,D) -> loss (...) or potentials."""
+    C_xy, C_yx = cost_matrix(x, y, p), cost_matrix(y, x, p)
+    C_xx, C_yy = (cost_matrix(x, x, p), cost_matrix(y, y, p)) if debias else (None, None)
+    diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+    pots, last = sinkhorn_loop(softmin_dense, [log_weights(a)], [log_weights(b)], [C_xx], [C_yy], [C_xy], [C_yx],
+                               eps_list, rho, debias=debias)
+    f_aa, g_bb, g_ab, f_ba = pots
+    out = sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
+    if return_internals:
+        return out, pots, last, (eps, rho, eps_list)
+    return out
+
+
+def sinkhorn_loss(x, y, a=None, b=None, dtype=np.float64, **kw):
+    """SamplesLoss("sinkhorn", backend="tensorized")(a, x, b, y) for float64 NumPy inputs."""
+    x, y = np.asarray(x, dtype), np.asarray(y, dtype)
+    a = _uniform(x.shape[-2], x.shape[:-2], dtype) if a is None else np.asarray(a, dtype)
+    b = _uniform(y.shape[-2], y.shape[:-2], dtype) if b is None else np.asarray(b, dtype)
+    out = sinkhorn_tensorized(a, x, b, y, **kw)
+    return float(out) if np.ndim(out) == 0 else out
+
+
+def sinkhorn_loss_and_grad(x, y, a=None, b=None, p=2, dtype=np.float64, **kw):
+    """Loss and its gradient with respect to x, a (balanced, closed form of SURVEY Appendix A):
+    autograd only sees the last soft-mins (sinkhorn_divergence.py:612-623) whose second cloud and
+    dual vector are detached, hence  dL/dx = a_i [ dF_ba/dx_i - dF_aa/dx_i ],  dL/da = f_ba - f_aa."""
+    x, y = np.asarray(x, dtype), np.asarray(y, dtype)
+    a = _uniform(x.shape[-2], x.shape[:-2], dtype) if a is None else np.asarray(a, dtype)
+    b = _uniform(y.shape[-2], y.shape[:-2], dtype) if b is None else np.asarray(b, dtype)
+    assert kw.get("reach") is None, "closed-form gradient restated for balanced OT only"
+    debias = kw.get("debias", True)
+    loss, pots, last, (eps, rho, _) = sinkhorn_tensorized(a, x, b, y, p=p, return_internals=True, **kw)
+    f_aa, g_bb, g_ab, f_ba = pots
+    gx = softmin_points_grad_x(eps, x, y, last["h_ba"], a, p=p, dtype=dtype)
+    ga = f_ba.copy()
+    if debias:
+        gx = gx - softmin_points_grad_x(eps, x, x, last["h_aa"], a, p=p, dtype=dtype)
+        ga = ga - f_aa
+    return loss, gx, ga
+
+
+# --------------------------------------------------------------------------------------------------
+#  kernel norms  (kernel_samples.py:62-146)
+# --------------------------------------------------------------------------------------------------
+
+
+def kernel_matrix(name, x, y, blur=0.05):
+    """gaussian_kernel :62-68, laplacian_kernel :71-77, energy_kernel :80-82 (explicit differences)."""
+    if name == "gaussian":
+        return np.exp(-squared_distances(x / blur, y / blur) / 2)
+    if name == "laplacian":
+        return np.exp(-distances(x / blur, y / blur))
+    if name == "energy":
+        return -distances(x, y)
+    raise KeyError(name)
+
+
+def kernel_conv(name, x, y, v, blur=0.05, row_block=2048):
+    """(K_xy @ v)_i, row-blocked."""
+    out = np.empty(x.shape[:-1], x.dtype)
+    for i0 in range(0, x.shape[-2], row_block):
+        K = kernel_matrix(name, x[..., i0:i0 + row_block, :], y, blur)
+        out[..., i0:i0 + row_block] = (K * v[..., None, :]).sum(-1)
+    return out
+
+
+def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, dtype=np.float64):
+    """kernel_loss, kernel_samples.py:92-146."""
+    x, y = np.asarray(x, dtype), np.asarray(y, dtype)
+    a = _uniform(x.shape[-2], x.shape[:-2], dtype) if a is None else np.asarray(a, dtype)
+    b = _uniform(y.shape[-2], y.shape[:-2], dtype) if b is None else np.asarray(b, dtype)
+    a_x = kernel_conv(name, x, x, a, blur)
+    b_y = kernel_conv(name, y, y, b, blur)
+    b_x = kernel_conv(name, x, y, b, blur)
+    if potentials:
+        a_y = kernel_conv(name, y, x, a, blur)
+        return a_x - b_x, b_y - a_y
+    out = 0.5 * scal(a, a_x) + 0.5 * scal(b, b_y) - scal(a, b_x)
+    return float(out) if np.ndim(out) == 0 else out
+
+
+def kernel_loss_grad_x(name, x, y, a=None, b=None, blur=0.05, dtype=np.float64):
+    """d loss / d x for un-batched clouds (DoubleGrad doubles the symmetric term)."""
+    x, y = np.asarray(x, dtype), np.asarray(y, dtype)
+    a = _uniform(x.shape[0], (), dtype) if a is None else np.asarray(a, dtype)
+    b = _uniform(y.shape[0], (), dtype) if b is None else np.asarray(b, dtype)
+
+    def dk(xa, ya, w):  # sum_j w_j dk/dx(x_i, y_j)
+        diff = xa[:, None, :] - ya[None, :, :]
+        d2 = (diff * diff).sum(-1)
+        if name == "gaussian":
+            coef = -np.exp(-d2 / (2 * blur**2)) / blur**2
+        else:  # the clamp of utils.py:61 acts on |x/blur - y/blur|^2 (laplacian) or |x - y|^2 (energy)
+            live = d2 > (1e-8 * blur**2 if name == "laplacian" else 1e-8)
+            d = np.sqrt(np.where(live, d2, 1.0))
+            inv = np.where(live, 1.0 / d, 0.0)
+            coef = -np.exp(-d / blur) * inv / blur if name == "laplacian" else -inv
+        return ((coef * w[None, :])[..., None] * diff).sum(1)
+
+    return a[:, None] * (dk(x, x, a) - dk(x, y, b))
+
+
+# --------------------------------------------------------------------------------------------------
+#  two-scale Sinkhorn  (sinkhorn_samples.py:453-681), dense emulation of the block-sparse reductions
+# --------------------------------------------------------------------------------------------------
+
+
+def grid_cluster(x, size):
+    """Voxel labels, compacted to 0..C-1 in lexicographic voxel order (pykeops.torch.cluster.grid_cluster
+    as used at sinkhorn_samples.py:477)."""
+    q = np.floor(x / size).astype(np.int64)
+    q -= q.min(0)
+    ext = q.max(0) + 1
+    code = q[:, 0]
+    for d in range(1, q.shape[1]):
+        code = code * ext[d] + q[:, d]
+    _, lab = np.unique(code, return_inverse=True)
+    return lab
+
+
+def clusterize(a, x, scale):
+    """sinkhorn_samples.py:453-490: sorted cloud, per-cluster ranges, weighted centroids, summed weights."""
+    lab = grid_cluster(x, scale)
+    counts = np.bincount(lab)
+    a_c = np.bincount(lab, weights=a)
+    x_c = np.stack([np.bincount(lab, weights=a * x[:, d]) for d in range(x.shape[1])], 1) / a_c[:, None]
+    ends = np.cumsum(counts)
+    ranges = np.stack([ends - counts, ends], 1)
+    perm = np.argsort(lab, kind="stable")
+    return a_c, a[perm], x_c, x[perm], ranges, perm
+
+
+def _expand_mask(keep, ranges_i, ranges_j, N, M):
+    """cluster-level keep mask -> point-level mask on the sorted clouds"""
+    li = np.repeat(np.arange(len(ranges_i)), ranges_i[:, 1] - ranges_i[:, 0])
+    lj = np.repeat(np.arange(len(ranges_j)), ranges_j[:, 1] - ranges_j[:, 0])
+    assert len(li) == N and len(lj) == M
+    return keep[li][:, lj]
+
+
+def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5,
+                        cluster_scale=None, debias=True, potentials=False, return_info=False):
+    """Two-scale Sinkhorn on dense matrices.  Cost objects are dicts {C, x, y, ranges_x, ranges_y}; a
+    truncated fine object carries C = +inf outside the kept blocks, so softmin_dense ignores those pairs
+    exactly as a block-sparse reduction does."""
+    N, D = x.shape
+    M = y.shape[0]
+    diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+    if cluster_scale is None:
+        cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))          # :584-585
+    a_c, a, x_c, x, ranges_x, perm_x = clusterize(a, x, cluster_scale)
+    b_c, b, y_c, y, ranges_y, perm_y = clusterize(b, y, cluster_scale)
+
+    jumps = [len(eps_list) - 1]                                              # :593-597
+    eps_cost = eps
+    for i, e in enumerate(eps_list[2:]):
+        eps_cost = e                                                         # the reference's shadowed `eps`
+        if cluster_scale**p > e:
+            jumps = [i + 1]
+            break
+
+    def obj(u, v, ru, rv):
+        return dict(C=cost_matrix(u, v, p), x=u, y=v, ranges_x=ru, ranges_y=rv)
+
+    def softmin(eps_, Cobj, h):
+        return softmin_dense(eps_, Cobj["C"], h)
+
+    def kernel_truncation(C_xy, C_yx, C_xy_f, C_yx_f, f, g, eps_, truncate=None, cost=None):
+        if truncate is None:
+            return C_xy_f, C_yx_f
+        keep = f[:, None] + g[None, :] > C_xy["C"] - truncate * eps_         # :512-514
+        mask = _expand_mask(keep, C_xy["ranges_x"], C_xy["ranges_y"], C_xy_f["C"].shape[0], C_xy_f["C"].shape[1])
+        info["kept_fraction"].append(float(mask.mean()))
+        out_xy = dict(C_xy_f, C=np.where(mask, C_xy_f["C"], np.inf))
+        out_yx = dict(C_yx_f, C=np.where(mask.T, C_yx_f["C"], np.inf))
+        return out_xy, out_yx
+
+    def extrapolate(f, g, eps_, lam, C_xy, b_log, C_xy_f):                   # :533-544
+        return lam * softmin_dense(eps_, cost_matrix(C_xy_f["x"], C_xy["y"], p), b_log + g / eps_)
+
+    info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), cluster_scale=cluster_scale, kept_fraction=[],
+                eps_list=eps_list)
+    C_xys = [obj(x_c, y_c, ranges_x, ranges_y), obj(x, y, None, None)]
+    C_yxs = [obj(y_c, x_c, ranges_y, ranges_x), obj(y, x, None, None)]
+    C_xxs = [obj(x_c, x_c, ranges_x, ranges_x), obj(x, x, None, None)] if debias else None
+    C_yys = [obj(y_c, y_c, ranges_y, ranges_y), obj(y, y, None, None)] if debias else None
+
+    pots, _ = sinkhorn_loop(softmin, [log_weights(a_c), log_weights(a)], [log_weights(b_c), log_weights(b)],
+                            C_xxs, C_yys, C_xys, C_yxs, eps_list, rho, jumps=jumps,
+                            kernel_truncation=kernel_truncation, truncate=truncate, extrapolate=extrapolate,
+                            debias=debias)
+    f_aa, g_bb, g_ab, f_ba = pots
+    out = sinkhorn_cost(eps_cost, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
+    if potentials:                                                           # :675-679
+        F, G = out
+        f_x, g_y = np.empty_like(F), np.empty_like(G)
+        f_x[perm_x], g_y[perm_y] = F, G
+        out = (f_x, g_y)
+    return (out, info) if return_info else out

@@ -1,0 +1,47 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def golden_cases():
+    out = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        name = os.path.basename(f)[:-4]
+        if name not in ("cfg1_n2000_d2", "softmin_tensorized"):
+            out.append(name)
+    return out
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    rec = {k: z[k] for k in z.files}
+    if "kwargs" in rec:
+        rec["kwargs"] = eval(str(rec["kwargs"]))  # written by make_golden.py as repr(dict)
+    return rec
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

@@ -1,0 +1,213 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle (float64 restatement of the reference).
+
+Tolerances: the kernels compute in fp32, the oracle in fp64.  Soft-min outputs are compared relative to
+the largest potential (max-norm): 2e-6 for p=2 (expanded form: abs error ~ diam^2 * 2^-23), which is
+far inside the 1e-4 relative budget BASELINE.json states for the loss.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from geomloss_amd import hip
+from geomloss_amd.cluster import from_matrix
+from oracle import oracle_c, oracle_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(seed, N, M, D, B=None, offset=0.0):
+    rng = np.random.default_rng(seed)
+    shp = (lambda n: (n, D)) if B is None else (lambda n: (B, n, D))
+    x = rng.random(shp(N)).astype(np.float32) + offset
+    y = (rng.random(shp(M)) * 0.8 + 0.1).astype(np.float32) + offset
+    h = rng.standard_normal(shp(M)[:-1]).astype(np.float32)
+    return x, y, h
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+SOFTMIN_SHAPES = [(300, 257, 3), (1030, 2100, 3), (513, 1025, 2), (700, 900, 1), (64, 8, 3), (1, 1, 3), (5, 3000, 2)]
+
+
+@pytest.mark.parametrize("N,M,D", SOFTMIN_SHAPES)
+@pytest.mark.parametrize("p", [2, 1])
+@pytest.mark.parametrize("eps", [1.0, 0.05**2])
+def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
+    x, y, h = _clouds(N + M + D, N, M, D)
+    ref = oracle_c.softmin(eps, x, y, h, p)
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p).cpu().numpy()
+    assert relerr(out, ref) < 2e-6
+    out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
+    assert relerr(out_d, ref) < 2e-6
+
+
+@pytest.mark.parametrize("N,M,D", [(300, 257, 3), (1030, 1100, 2), (200, 300, 1)])
+@pytest.mark.parametrize("p", [2, 1])
+def test_softmin_bwd_vs_oracle(cuda, N, M, D, p):
+    eps = 0.01
+    x, y, h = _clouds(7 * N + D, N, M, D)
+    g = np.random.default_rng(3).standard_normal(N).astype(np.float32)
+    ref = oracle_c.softmin_grad_x(eps, x, y, h, g, p)
+    xt = _t(x, cuda).requires_grad_(True)
+    out = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=p)
+    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
+    assert relerr(gx.cpu().numpy(), ref) < 5e-6
+
+
+def test_softmin_batched_and_bf16(cuda):
+    B, N, M, D = 5, 300, 400, 3
+    x, y, h = _clouds(11, N, M, D, B=B)
+    eps = 0.05**2
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
+    for b in range(B):
+        assert relerr(out[b], oracle_c.softmin(eps, x[b], y[b], h[b], 2)) < 2e-6
+    # bf16 points: kernel widens to fp32, so parity is against the oracle on the bf16-rounded points
+    xb, yb = _t(x, cuda).bfloat16(), _t(y, cuda).bfloat16()
+    out16 = hip.softmin(eps, xb, yb, _t(h, cuda)).cpu().numpy()
+    xr, yr = xb.float().cpu().numpy(), yb.float().cpu().numpy()
+    for b in range(B):
+        assert relerr(out16[b], oracle_c.softmin(eps, xr[b], yr[b], h[b], 2)) < 2e-6
+
+
+def test_softmin_translation_robust(cuda):
+    """Clouds far from the origin: the per-workgroup re-centring keeps the expanded form accurate."""
+    x, y, h = _clouds(5, 600, 700, 3, offset=1000.0)
+    eps = 0.05**2
+    ref = oracle_c.softmin(eps, x, y, h, 2)
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
+    assert np.abs(out - ref).max() < 1e-5   # potentials are O(1): absolute tolerance
+
+
+def test_softmin_rescale_branch_and_infinities(cuda):
+    """Running max must survive a late, much larger exponent and -inf / -1e5 dual values."""
+    N, M, D = 130, 2500, 3
+    x, y, h = _clouds(9, N, M, D)
+    h[:] = -50.0
+    h[-1] = 80.0            # the maximum arrives in the last chunk of the last tile
+    h[5] = -np.inf
+    h[6] = -100000.0
+    eps = 0.05**2
+    ref = oracle_c.softmin(eps, x, y, h, 2)
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
+    assert np.isfinite(out).all() and relerr(out, ref) < 2e-6
+
+
+def _random_ranges(rng, N, M, ci, cj, density, dev):
+    cut_i = np.sort(rng.choice(np.arange(1, N), ci - 1, replace=False))
+    cut_j = np.sort(rng.choice(np.arange(1, M), cj - 1, replace=False))
+    ri = np.stack([np.r_[0, cut_i], np.r_[cut_i, N]], 1).astype(np.int32)
+    rj = np.stack([np.r_[0, cut_j], np.r_[cut_j, M]], 1).astype(np.int32)
+    keep = rng.random((ci, cj)) < density
+    keep[0, :] = False      # one row block with nothing to reduce over
+    keep[1, :] = True
+    rg = from_matrix(torch.from_numpy(ri).to(dev), torch.from_numpy(rj).to(dev), torch.from_numpy(keep).to(dev))
+    tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    tup_t = tuple(t.cpu().numpy() for t in (rg.ranges_j, rg.slices_j, rg.redranges_i))
+    return rg, tup, tup_t, keep, ri
+
+
+@pytest.mark.parametrize("p", [2, 1])
+def test_softmin_block_sparse_vs_oracle(cuda, p):
+    rng = np.random.default_rng(17)
+    N, M, D = 2300, 2600, 3
+    x, y, h = _clouds(23, N, M, D)
+    rg, tup, _, keep, ri = _random_ranges(rng, N, M, 9, 11, 0.4, cuda)
+    eps = 0.02
+    ref = oracle_c.softmin(eps, x, y, h, p, ranges=tup)
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, ranges=rg).cpu().numpy()
+    empty = slice(ri[0, 0], ri[0, 1])
+    assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()   # LSE over the empty set
+    live = np.ones(N, bool)
+    live[empty] = False
+    assert relerr(out[live], ref[live]) < 2e-6
+    g = rng.standard_normal(N).astype(np.float32)
+    g[empty] = 0
+    xt = _t(x, cuda).requires_grad_(True)
+    o = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=p, ranges=rg)
+    (gx,) = torch.autograd.grad(o[torch.from_numpy(live).to(cuda)], [xt], grad_outputs=_t(g[live], cuda))
+    refg = oracle_c.softmin_grad_x(eps, x, y, h, g, p, ranges=tup)
+    assert relerr(gx.cpu().numpy()[live], refg[live]) < 5e-6
+
+
+KINDS = ["gaussian", "laplacian", "energy"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("N,M,D", [(300, 257, 3), (1030, 2100, 2), (200, 300, 1), (150, 170, 6)])
+def test_kernel_conv_vs_oracle(cuda, kind, N, M, D):
+    x, y, v = _clouds(31 + N, N, M, D)
+    blur = 0.2
+    ref = oracle_c.kconv(kind, x, y, v, blur)
+    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur).cpu().numpy()
+    assert relerr(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("D", [3, 2, 5])
+def test_kernel_conv_grads_vs_oracle(cuda, kind, D):
+    N, M = 310, 270
+    x, y, v = _clouds(41 + D, N, M, D)
+    y[:7] = x[:7]    # coincident points: |x-y| = 0 must give a zero direction, not NaN
+    blur = 0.15
+    g = np.random.default_rng(4).standard_normal(N).astype(np.float32)
+    xt, yt, vt = (_t(a, cuda).requires_grad_(True) for a in (x, y, v))
+    out = hip.kernel_conv(kind, xt, yt, vt, blur)
+    gx, gy, gv = torch.autograd.grad(out, [xt, yt, vt], grad_outputs=_t(g, cuda))
+    assert relerr(gx.cpu().numpy(), oracle_c.kconv_grad_x(kind, x, y, v, g, blur)) < 5e-6
+    assert relerr(gy.cpu().numpy(), oracle_c.kconv_grad_x(kind, y, x, g, v, blur)) < 5e-6
+    assert relerr(gv.cpu().numpy(), oracle_c.kconv(kind, y, x, g, blur)) < 5e-6
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_kernel_conv_block_sparse(cuda, kind):
+    rng = np.random.default_rng(19)
+    N, M, D = 1900, 2100, 3
+    x, y, v = _clouds(29, N, M, D)
+    rg, tup, tup_t, keep, ri = _random_ranges(rng, N, M, 8, 7, 0.5, cuda)
+    blur = 0.3
+    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg).cpu().numpy()
+    assert relerr(out, oracle_c.kconv(kind, x, y, v, blur, ranges=tup)) < 3e-6
+    # transposed pattern (K^T @ g)
+    g = rng.standard_normal(N).astype(np.float32)
+    out_t = hip.kernel_conv(kind, _t(y, cuda), _t(x, cuda), _t(g, cuda), blur, ranges=rg.t()).cpu().numpy()
+    assert relerr(out_t, oracle_c.kconv(kind, y, x, g, blur, ranges=tup_t)) < 3e-6
+
+
+@pytest.mark.parametrize("D", [4, 7, 16, 33])
+@pytest.mark.parametrize("p", [2, 1])
+def test_generic_dimension_softmin(cuda, D, p):
+    N, M = 270, 310
+    x, y, h = _clouds(51 + D, N, M, D)
+    eps = 0.3
+    ref = oracle_c.softmin(eps, x, y, h, p)
+    xt = _t(x, cuda).requires_grad_(True)
+    out = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=p)
+    assert relerr(out.detach().cpu().numpy(), ref) < 3e-6
+    g = np.random.default_rng(6).standard_normal(N).astype(np.float32)
+    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
+    assert relerr(gx.cpu().numpy(), oracle_c.softmin_grad_x(eps, x, y, h, g, p)) < 5e-6
+
+
+def test_dense_softmin_vs_oracle(cuda):
+    rng = np.random.default_rng(2)
+    for (B, N, M) in [(2, 130, 1024), (1, 77, 333), (3, 5, 7)]:
+        C = rng.random((B, N, M)).astype(np.float32) * 3
+        h = rng.standard_normal((B, M)).astype(np.float32)
+        for eps in (1.0, 0.01):
+            ref = oracle_np.softmin_dense(eps, C.astype(np.float64), h.astype(np.float64))
+            out = hip.softmin_dense(eps, _t(C, cuda), _t(h, cuda)).cpu().numpy()
+            assert relerr(out, ref) < 2e-6
+
+
+def test_c_abi_error_codes(cuda):
+    lib = hip.load_library()
+    x = torch.rand(10, 3, device=cuda)
+    with pytest.raises(NotImplementedError):
+        hip.softmin(0.1, x, x, torch.zeros(10, device=cuda), p=3)
+    with pytest.raises(ValueError):
+        hip.softmin(-1.0, x, x, torch.zeros(10, device=cuda), p=2)
+    assert lib.glhip_version() >= 100

@@ -1,0 +1,56 @@
+"""Quick kernel timings on one GPU (development aid; bench.py is the contract)."""
+import argparse
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from geomloss_amd import hip
+
+
+def timeit(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="100000,1000000")
+    ap.add_argument("--what", default="softmin,softmin_direct,softmin_p1,bwd,gauss,lap,energy")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
+    for N in [int(s) for s in args.sizes.split(",")]:
+        torch.manual_seed(0)
+        x, y = torch.rand(N, 3, device=dev), torch.rand(N, 3, device=dev)
+        eps = 0.05**2
+        h = torch.full((N,), -float(torch.log(torch.tensor(float(N)))), device=dev) + 0.01 * torch.randn(N, device=dev) / eps
+        xb, yb, hb = x[None], y[None], h[None]
+        pairs = float(N) * N
+        what = args.what.split(",")
+        res = {}
+        if "softmin" in what:
+            res["softmin p2"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
+        if "softmin_direct" in what:
+            res["softmin p2 direct"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=1))
+        if "softmin_p1" in what:
+            res["softmin p1"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, 0.05, 1))
+        if "bwd" in what:
+            out = hip.softmin_fwd_raw(xb, yb, hb, eps, 2)
+            g = torch.ones_like(out)
+            res["softmin bwd p2"] = timeit(lambda: hip.softmin_bwd_x_raw(xb, yb, hb, out, g, eps, 2))
+        v = torch.full((1, N), 1.0 / N, device=dev)
+        for nm, kind in (("gauss", 0), ("lap", 1), ("energy", 2)):
+            if nm in what:
+                res["conv " + nm] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05))
+        for k, (tmin, tmed) in res.items():
+            print(f"N=M={N:>8d} {k:20s} min {tmin*1e3:10.3f} ms  med {tmed*1e3:10.3f} ms  {pairs/tmin:.3e} pairs/s")
+
+
+if __name__ == "__main__":
+    main()
