@@ -87,6 +87,13 @@ def _exponent_of(cost_formula):
     )
 
 
+def _fp32_weights(a, b):
+    """bf16 / fp16 clouds are read as such by the kernels, but weights, dual potentials and the loss stay fp32."""
+    if a.dtype in (torch.bfloat16, torch.float16):
+        a, b = a.float(), b.float()
+    return a, b
+
+
 def softmin_online(eps, C_xy, h_y, p=2):
     """Soft-C-transform on implicit costs (``:337-346`` and ``:229-290``): C_xy = (x, y), batched or not."""
     x, y = C_xy
@@ -100,6 +107,7 @@ def sinkhorn_online(
 ):
     """Sinkhorn divergence with O(N+M) memory; a (B,N), x (B,N,D), b (B,M), y (B,M,D) on a GPU."""
     B = x.shape[0]
+    a, b = _fp32_weights(a, b)
     if cost is not None:
         if B > 1:
             raise ValueError("Custom cost functions are not yet supported with batches." "")
@@ -175,6 +183,7 @@ def sinkhorn_multiscale(
 ):
     """Two-scale Sinkhorn divergence; a (N,), x (N,D), b (M,), y (M,D) on a GPU (``:547-681``)."""
     N, D = x.shape
+    a, b = _fp32_weights(a, b)
     if cost is None:
         cost = cost_formulas[p], cost_routines[p]
     cost_formula, cost_routine = cost[0], cost[1]

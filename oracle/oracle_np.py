@@ -259,7 +259,7 @@ def sinkhorn_loss(x, y, a=None, b=None, dtype=np.float64, **kw):
     a = _uniform(x.shape[-2], x.shape[:-2], dtype) if a is None else np.asarray(a, dtype)
     b = _uniform(y.shape[-2], y.shape[:-2], dtype) if b is None else np.asarray(b, dtype)
     out = sinkhorn_tensorized(a, x, b, y, **kw)
-    return float(out) if np.ndim(out) == 0 else out
+    return float(out) if not isinstance(out, tuple) and np.ndim(out) == 0 else out
 
 
 def sinkhorn_loss_and_grad(x, y, a=None, b=None, p=2, dtype=np.float64, **kw):

@@ -1,0 +1,75 @@
+"""World-size-2 `gloo` test of the batch-sharded loss (the N>1 path of bench.py uses the same module on RCCL)."""
+
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geomloss_amd import SamplesLoss
+        from geomloss_amd.distributed import ShardedSamplesLoss, shard_batch, shard_bounds
+
+        torch.manual_seed(0)
+        B, N, M = 5, 40, 50   # odd batch: ranks own 3 and 2 items
+        x = torch.rand(B, N, 2)
+        y = torch.rand(B, M, 2) * torch.linspace(0.5, 1.5, B)[:, None, None]   # heterogeneous boxes
+        base = SamplesLoss("sinkhorn", p=2, blur=0.1, backend="tensorized")
+        full = base(x, y)   # unsharded reference: one schedule from the global bounding box
+
+        xl = shard_batch(x).clone().requires_grad_(True)
+        yl = shard_batch(y)
+        lo, hi = shard_bounds(B, rank, world)
+        total = ShardedSamplesLoss(base, "sum")(xl, yl)
+        (g,) = torch.autograd.grad(total, [xl])
+        xf = x.clone().requires_grad_(True)
+        (gf,) = torch.autograd.grad(base(xf, y).sum(), [xf])
+        vec = ShardedSamplesLoss(base, "none")(xl.detach(), yl)
+        mean = ShardedSamplesLoss(base, "mean")(xl.detach(), yl)
+        q.put((rank, float((total - full.sum()).abs() / full.sum().abs()), float((g - gf[lo:hi]).abs().max()),
+               float((vec - full).abs().max()), float((mean - full.mean()).abs()), None))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, None, None, None, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loss_equals_unsharded_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, rel_total, gerr, verr, merr, err in results:
+        assert err is None, f"rank {rank}: {err}"
+        assert rel_total < 1e-6 and gerr < 1e-6 and verr < 1e-6 and merr < 1e-6
+
+
+def test_shard_bounds_partition_the_batch():
+    from geomloss_amd.distributed import shard_bounds
+    for B in (1, 7, 8, 256):
+        for W in (1, 2, 4, 8):
+            cuts = [shard_bounds(B, r, W) for r in range(W)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+            assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1

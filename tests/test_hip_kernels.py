@@ -1,8 +1,12 @@
 """GPU parity of every C-ABI entry point against the CPU oracle (float64 restatement of the reference).
 
-Tolerances: the kernels compute in fp32, the oracle in fp64.  Soft-min outputs are compared relative to
-the largest potential (max-norm): 2e-6 for p=2 (expanded form: abs error ~ diam^2 * 2^-23), which is
-far inside the 1e-4 relative budget BASELINE.json states for the loss.
+Tolerances: the kernels compute in fp32, the oracle in fp64.
+* DIRECT form (p=1, or p=2 with FLAG_DIRECT): max-norm relative error < 2e-6.
+* EXPANDED form (p=2 default): the exponent is a sum of terms of size diam^2/eps, so the potential
+  carries an ABSOLUTE error of a few 2^-24 * diam^2 whatever eps is (the reference's dense fp32 cost
+  |x|^2 - 2x.y + |y|^2 has the same property).  Bound used: 4e-7 * diam^2 plus the 2e-6 relative term.
+Both are far inside the 1e-4 relative budget BASELINE.json states for the loss; the loss-level check is
+tests/test_samples_loss_gpu.py.
 """
 
 import numpy as np
@@ -40,7 +44,7 @@ def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
     x, y, h = _clouds(N + M + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, p)
     out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p).cpu().numpy()
-    assert relerr(out, ref) < 2e-6
+    assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max()     # diam^2 <= D on the unit cube
     out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
     assert relerr(out_d, ref) < 2e-6
 
@@ -64,13 +68,13 @@ def test_softmin_batched_and_bf16(cuda):
     eps = 0.05**2
     out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
     for b in range(B):
-        assert relerr(out[b], oracle_c.softmin(eps, x[b], y[b], h[b], 2)) < 2e-6
+        assert np.abs(out[b] - oracle_c.softmin(eps, x[b], y[b], h[b], 2)).max() < 1.2e-6
     # bf16 points: kernel widens to fp32, so parity is against the oracle on the bf16-rounded points
     xb, yb = _t(x, cuda).bfloat16(), _t(y, cuda).bfloat16()
     out16 = hip.softmin(eps, xb, yb, _t(h, cuda)).cpu().numpy()
     xr, yr = xb.float().cpu().numpy(), yb.float().cpu().numpy()
     for b in range(B):
-        assert relerr(out16[b], oracle_c.softmin(eps, xr[b], yr[b], h[b], 2)) < 2e-6
+        assert np.abs(out16[b] - oracle_c.softmin(eps, xr[b], yr[b], h[b], 2)).max() < 1.2e-6
 
 
 def test_softmin_translation_robust(cuda):
@@ -93,7 +97,7 @@ def test_softmin_rescale_branch_and_infinities(cuda):
     eps = 0.05**2
     ref = oracle_c.softmin(eps, x, y, h, 2)
     out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
-    assert np.isfinite(out).all() and relerr(out, ref) < 2e-6
+    assert np.isfinite(out).all() and np.abs(out - ref).max() < 1.2e-6 + 2e-6 * np.abs(ref).max()
 
 
 def _random_ranges(rng, N, M, ci, cj, density, dev):
@@ -123,7 +127,7 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()   # LSE over the empty set
     live = np.ones(N, bool)
     live[empty] = False
-    assert relerr(out[live], ref[live]) < 2e-6
+    assert np.abs(out[live] - ref[live]).max() < 1.2e-6 + 2e-6 * np.abs(ref[live]).max()
     g = rng.standard_normal(N).astype(np.float32)
     g[empty] = 0
     xt = _t(x, cuda).requires_grad_(True)

@@ -1,0 +1,207 @@
+"""CPU tests of the host side: SamplesLoss mirror (shapes, errors, dispatch), tensorized path vs the
+reference's golden outputs, epsilon schedule, clustering / range helpers, C-ABI symbols.  No GPU."""
+
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_cases, load_golden, relerr
+from geomloss_amd import SamplesLoss, hip
+from geomloss_amd import sinkhorn_divergence as sd
+from geomloss_amd.cluster import cluster_ranges_centroids, from_matrix, grid_cluster
+from oracle import oracle_np
+
+
+# ---- tensorized path == reference (fp32 bit-level on cfg 1, 1e-6 elsewhere) --------------------
+
+def test_cfg1_tensorized_cpu_equals_reference_fp32():
+    rec = load_golden("cfg1_n2000_d2")
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="tensorized")(torch.from_numpy(rec["x"]), torch.from_numpy(rec["y"]))
+    assert L.item() == pytest.approx(float(rec["loss_f32"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_tensorized_cpu_matches_golden(name):
+    rec = load_golden(name)
+    a, x, b, y = (torch.from_numpy(rec[k]).float() for k in "axby")
+    x.requires_grad_(True)
+    L = SamplesLoss(backend="tensorized", **rec["kwargs"])(a, x, b, y)
+    assert relerr(L.detach().numpy(), rec["loss_f32"]) < 2e-5
+    (gx,) = torch.autograd.grad(L.sum(), [x])
+    assert relerr(gx.numpy(), rec["gx_f32"]) < 2e-4
+    F, G = SamplesLoss(backend="tensorized", potentials=True, **rec["kwargs"])(a, x.detach(), b, y)
+    assert F.shape == rec["F_f32"].shape and G.shape == rec["G_f32"].shape  # incl. the (1,N) quirk
+    assert relerr(F.numpy(), rec["F_f32"]) < 2e-5
+
+
+def test_epsilon_schedule_lengths_match_survey_probe():
+    # 7 (D=2 unit square), 8 (D=3 unit cube), 7 (diameter=1), 9 (blur=.01), 36 (scaling .9)
+    assert len(sd.epsilon_schedule(2, np.sqrt(2), 0.05, 0.5)) == 7
+    assert len(sd.epsilon_schedule(2, np.sqrt(3), 0.05, 0.5)) == 8
+    assert len(sd.epsilon_schedule(2, 1.0, 0.05, 0.5)) == 7
+    assert len(sd.epsilon_schedule(2, 1.0, 0.01, 0.5)) == 9
+    assert len(sd.epsilon_schedule(2, np.sqrt(3), 0.05, 0.9)) == 36
+    assert sd.epsilon_schedule(2, 1.7, 0.05, 0.5) == oracle_np.epsilon_schedule(2, 1.7, 0.05, 0.5)
+
+
+def test_log_weights_and_dampening():
+    a = torch.tensor([0.5, 0.0, 0.5])
+    assert sd.log_weights(a).tolist() == [pytest.approx(np.log(0.5)), -100000.0, pytest.approx(np.log(0.5))]
+    assert sd.dampening(0.1, None) == 1 and sd.dampening(0.5, 2.0) == pytest.approx(0.8)
+    # gradients go through the forward factor rho + eps/2 (reference quirk)
+    w = sd.UnbalancedWeight(0.5, 2.0)
+    t = torch.ones(1, requires_grad=True)
+    w(t).backward()
+    assert t.grad.item() == pytest.approx(2.25)
+
+
+def test_sinkhorn_loop_leaves_grad_enabled():
+    x, y = torch.rand(20, 2), torch.rand(30, 2)
+    with torch.no_grad():
+        SamplesLoss("sinkhorn", backend="tensorized")(x, y)
+        assert torch.is_grad_enabled()  # reference behaviour: sinkhorn_divergence.py:434,612
+
+
+# ---- shapes, call forms, error messages ---------------------------------------------------------
+
+def test_call_forms_and_output_shapes():
+    L = SamplesLoss("gaussian", blur=0.5, backend="tensorized")
+    x, y = torch.rand(10, 3), torch.rand(12, 3)
+    a, b = torch.full((10,), 0.1), torch.full((12,), 1 / 12)
+    assert L(x, y).shape == () and L(a, x, b, y).shape == ()
+    assert L(a[:, None], x, b[:, None], y).item() == pytest.approx(L(a, x, b, y).item())
+    xb, yb = torch.rand(4, 10, 3), torch.rand(4, 12, 3)
+    assert L(xb, yb).shape == (4,)
+    assert L(a.expand(4, 10)[..., None], xb, b.expand(4, 12)[..., None], yb).shape == (4,)
+    F, G = SamplesLoss("sinkhorn", potentials=True, backend="tensorized")(x, y)
+    assert F.shape == (1, 10) and G.shape == (1, 12)  # reference quirk: view_as the unsqueezed weights
+    with pytest.raises(ValueError, match="two .x, y., four"):
+        L(x, y, x)
+
+
+@pytest.mark.parametrize("args,msg", [
+    (lambda: (torch.rand(5), torch.rand(5, 2), torch.rand(6, 1), torch.rand(6, 2)), "same number of dimensions"),
+    (lambda: (torch.rand(5), torch.rand(5, 2), torch.rand(6), torch.rand(1, 6, 2)), "samples 'x' and 'y' should have the same number"),
+    (lambda: (torch.rand(5), torch.rand(5, 2), torch.rand(6), torch.rand(6, 3)), "same last dimension"),
+    (lambda: (torch.rand(5, 2), torch.rand(5, 2), torch.rand(6, 2), torch.rand(6, 2)), r"'α' should be encoded as \(N,\) or \(N,1\)"),
+    (lambda: (torch.rand(4), torch.rand(5, 2), torch.rand(6), torch.rand(6, 2)), "Weights 'α' and samples 'x'"),
+    (lambda: (torch.rand(5), torch.rand(5, 2), torch.rand(7), torch.rand(6, 2)), "Weights 'β' and samples 'y'"),
+    (lambda: (torch.rand(2, 5), torch.rand(2, 5, 2), torch.rand(3, 6), torch.rand(3, 6, 2)), "same batchsize"),
+    (lambda: (torch.rand(5), torch.rand(5), torch.rand(5), torch.rand(5)), r"\(N,D\) or \(B,N,D\)"),
+])
+def test_shape_errors(args, msg):
+    with pytest.raises(ValueError, match=msg):
+        SamplesLoss("energy", backend="tensorized")(*args())
+
+
+def test_labels_and_backend_rules():
+    x, y = torch.rand(5, 2), torch.rand(6, 2)
+    a, b = torch.full((5,), 0.2), torch.full((6,), 1 / 6)
+    with pytest.raises(ValueError, match="Explicit cluster labels"):
+        SamplesLoss("sinkhorn", backend="online")(torch.zeros(5).int(), a, x, torch.zeros(6).int(), b, y)
+    with pytest.raises(ValueError, match="labels 'l_x' should have the same length"):
+        SamplesLoss("sinkhorn", backend="multiscale")(torch.zeros(4).int(), a, x, None, b, y)
+    with pytest.raises(NotImplementedError, match="not been implemented with batches"):
+        SamplesLoss("sinkhorn")(torch.zeros(1, 5), a[None], x[None], None, b[None], y[None])
+    with pytest.raises(KeyError):  # reference: "hausdorff" has no kernel name -> KeyError(None)
+        SamplesLoss("hausdorff", backend="tensorized")(x, y)
+
+
+def test_auto_backend_heuristic():
+    L = SamplesLoss("sinkhorn")
+    assert L._choose_backend(None, None, 0, 5000, 5000, 3) == "tensorized"
+    assert L._choose_backend(None, None, 0, 5001, 5000, 3) == "online"
+    assert L._choose_backend(None, None, 0, 10001, 10000, 3) == "multiscale"
+    assert L._choose_backend(None, None, 0, 10001, 10000, 4) == "online"
+    assert SamplesLoss("sinkhorn", p=1)._choose_backend(None, None, 0, 20000, 20000, 3) == "online"
+    assert SamplesLoss("gaussian")._choose_backend(None, None, 0, 20000, 20000, 3) == "online"
+
+
+def test_multiscale_with_batch_warns_and_falls_back_to_tensorized():
+    xb, yb = torch.rand(2, 30, 2), torch.rand(2, 40, 2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = SamplesLoss("sinkhorn", backend="multiscale")(xb, yb)
+    assert out.shape == (2,) and any("do not support batchsize" in str(m.message) for m in w)
+
+
+def test_hip_backends_refuse_cpu_tensors_loudly():
+    x, y = torch.rand(50, 3), torch.rand(60, 3)
+    for backend in ("online", "multiscale"):
+        with pytest.raises(RuntimeError, match="need GPU tensors|HIP extension"):
+            SamplesLoss("sinkhorn", backend=backend)(x, y)
+    with pytest.raises(RuntimeError, match="need GPU tensors|HIP extension"):
+        SamplesLoss("gaussian", backend="online")(x, y)
+    with pytest.raises(NotImplementedError, match="cost formulas"):
+        SamplesLoss("sinkhorn", backend="online", cost="Exp(X-Y)")(x, y)
+
+
+# ---- clustering and block-sparse ranges ----------------------------------------------------------
+
+def test_grid_cluster_and_centroids_match_oracle():
+    rng = np.random.default_rng(0)
+    x = rng.random((500, 3)).astype(np.float32)
+    a = rng.random(500).astype(np.float32)
+    a /= a.sum()
+    lab = grid_cluster(torch.from_numpy(x), 0.3).numpy()
+    assert (lab == oracle_np.grid_cluster(x, np.float32(0.3))).all()
+    ranges, xc, ac = cluster_ranges_centroids(torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(a))
+    a_c, _, x_c, _, rng_o, _ = oracle_np.clusterize(a.astype(np.float64), x.astype(np.float64), 0.3)
+    assert (ranges.numpy() == rng_o).all()
+    assert relerr(xc.numpy(), x_c) < 1e-5 and relerr(ac.numpy(), a_c) < 1e-5
+
+
+def test_from_matrix_covers_exactly_the_kept_pairs_in_both_orientations():
+    rng = np.random.default_rng(1)
+    ci, cj = 7, 9
+    si, sj = rng.integers(1, 6, ci), rng.integers(1, 6, cj)
+    ri = torch.tensor(np.stack([np.cumsum(si) - si, np.cumsum(si)], 1), dtype=torch.int32)
+    rj = torch.tensor(np.stack([np.cumsum(sj) - sj, np.cumsum(sj)], 1), dtype=torch.int32)
+    keep = torch.from_numpy(rng.random((ci, cj)) < 0.5)
+    keep[2] = False
+    rg = from_matrix(ri, rj, keep)
+
+    def covered(ranges_i, slices_i, red_j, n_i, n_j):
+        m = np.zeros((n_i, n_j), int)
+        for k in range(len(ranges_i)):
+            q0 = 0 if k == 0 else int(slices_i[k - 1])
+            for q in range(q0, int(slices_i[k])):
+                m[ranges_i[k, 0]:ranges_i[k, 1], red_j[q, 0]:red_j[q, 1]] += 1
+        return m
+
+    N, M = int(si.sum()), int(sj.sum())
+    want = oracle_np._expand_mask(keep.numpy(), ri.numpy(), rj.numpy(), N, M).astype(int)
+    got = covered(rg.ranges_i.numpy(), rg.slices_i.numpy(), rg.redranges_j.numpy(), N, M)
+    assert (got == want).all()  # every kept pair exactly once, nothing else
+    got_t = covered(rg.ranges_j.numpy(), rg.slices_j.numpy(), rg.redranges_i.numpy(), M, N)
+    assert (got_t == want.T).all()
+    # adjacent kept clusters are merged into one interval
+    n_runs = sum(len(re.findall("1+", "".join("1" if v else "0" for v in row))) for row in keep.numpy())
+    assert rg.redranges_j.shape[0] == n_runs
+
+
+# ---- C-ABI ------------------------------------------------------------------------------------------
+
+def test_shared_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "glhip.h")).read()
+    declared = set(re.findall(r"\b(glhip_\w+)\s*\(", header))
+    assert declared == set(hip.SIGNATURES), "include/glhip.h and geomloss_amd/hip.py disagree"
+    assert hip.library_available(), "libgeomloss_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is not exported"
+    lib.glhip_version.restype = ctypes.c_int
+    assert lib.glhip_version() == int(re.search(r"#define GLHIP_VERSION (\d+)", header).group(1))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "geomloss_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"

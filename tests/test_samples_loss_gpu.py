@@ -1,0 +1,189 @@
+"""GPU parity of the drop-in ``SamplesLoss`` (HIP backends) against the reference's golden outputs and the
+oracle.  The bar (BASELINE.json): loss within 1e-4 relative of the reference's tensorized backend, fp32."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden, relerr
+from geomloss_amd import SamplesLoss, hip
+from oracle import oracle_c, oracle_np
+
+pytestmark = pytest.mark.gpu
+
+SINKHORN = [n for n in golden_cases() if n.startswith("sinkhorn")]
+KERNELS = [n for n in golden_cases() if not n.startswith("sinkhorn")]
+
+
+def _inputs(rec, dev, grad=True):
+    a, x, b, y = (torch.from_numpy(rec[k]).float().to(dev) for k in "axby")
+    if grad:
+        x.requires_grad_(True)
+        a.requires_grad_(True)
+    return a, x, b, y
+
+
+@pytest.mark.parametrize("backend", ["online", "tensorized"])
+@pytest.mark.parametrize("name", SINKHORN)
+def test_sinkhorn_matches_reference(cuda, name, backend):
+    rec = load_golden(name)
+    a, x, b, y = _inputs(rec, cuda)
+    L = SamplesLoss(backend=backend, **rec["kwargs"])(a, x, b, y)
+    # p=1: the reference's own fp32 run is 3e-4 off its fp64 run (cancellation in the dense cost); our
+    # kernels evaluate distances on differences, so they are compared with the fp64 reference.
+    ref = "f64" if rec["kwargs"]["p"] == 1 and backend == "online" else "f32"
+    assert relerr(L.detach().cpu().numpy(), rec["loss_" + ref]) < 1e-4
+    assert relerr(L.detach().cpu().numpy(), rec["loss_f64"]) < 1e-4 or rec["kwargs"]["p"] == 1
+    gx, ga = torch.autograd.grad(L.sum(), [x, a])
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < 1e-3
+    assert relerr(ga.cpu().numpy(), rec["ga_f64"]) < 1e-4
+    F, G = SamplesLoss(backend=backend, potentials=True, **rec["kwargs"])(a.detach(), x.detach(), b, y)
+    assert F.shape == rec["F_f64"].shape
+    assert relerr(F.cpu().numpy(), rec["F_f64"]) < 1e-4 and relerr(G.cpu().numpy(), rec["G_f64"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", KERNELS)
+def test_kernel_losses_match_reference(cuda, name):
+    rec = load_golden(name)
+    a, x, b, y = _inputs(rec, cuda)
+    L = SamplesLoss(backend="online", **rec["kwargs"])(a, x, b, y)
+    assert relerr(L.detach().cpu().numpy(), rec["loss_f64"]) < 1e-4
+    gx, ga = torch.autograd.grad(L.sum(), [x, a])
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < 1e-4
+    assert relerr(ga.cpu().numpy(), rec["ga_f64"]) < 1e-4
+    F, G = SamplesLoss(backend="online", potentials=True, **rec["kwargs"])(a.detach(), x.detach(), b, y)
+    assert relerr(F.cpu().numpy(), rec["F_f64"]) < 1e-4 and relerr(G.cpu().numpy(), rec["G_f64"]) < 1e-4
+
+
+def test_cfg1_inputs_on_the_online_backend(cuda):
+    """BASELINE configs[0] inputs (N=M=2000, 2D, same-law clouds: loss 2e-4 is a difference of O(1e-2) terms)."""
+    rec = load_golden("cfg1_n2000_d2")
+    x, y = torch.from_numpy(rec["x"]).to(cuda), torch.from_numpy(rec["y"]).to(cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online")(x, y).item()
+    assert abs(L - float(rec["loss_f64"])) / float(rec["loss_f64"]) < 1e-4
+    F, G = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online", potentials=True)(x, y)
+    assert relerr(F.cpu().numpy().ravel(), rec["F_f64"].ravel()) < 1e-4
+
+
+def _two_clouds(seed, N, M, D=3, kind="shifted"):
+    rng = np.random.default_rng(seed)
+    x = rng.random((N, D)).astype(np.float32)
+    y = rng.random((M, D)).astype(np.float32)
+    if kind == "shifted":
+        y = y * 0.5 + np.float32(0.4)
+    return x, y
+
+
+@pytest.mark.parametrize("kind,scaling", [("shifted", 0.5), ("same", 0.7), ("shifted", 0.9)])
+def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling):
+    """cfg-3 parity: same clustering, same truncation rule, same loop as the reference's
+    two-scale algorithm, emulated in fp64 with dense masked matrices."""
+    N, M = 3500, 3000
+    x, y = _two_clouds(3, N, M, kind=kind)
+    a, b = np.full(N, 1 / N), np.full(M, 1 / M)
+    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
+                                              scaling=scaling, truncate=5, return_info=True)
+    assert info["jumps"][0] < len(info["eps_list"]) - 1 and 0 < info["kept_fraction"][0] < 1
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    yt = torch.from_numpy(y).to(cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=scaling, backend="multiscale")(xt, yt)
+    assert abs(L.item() - ref) / abs(ref) < 1e-4
+    (gx,) = torch.autograd.grad(L, [xt])
+    assert torch.isfinite(gx).all()
+    # potentials come back in the caller's point order
+    Fm, Gm = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=scaling, backend="multiscale", potentials=True)(xt.detach(), yt)
+    Fo, Go = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
+                                           scaling=scaling, truncate=5, potentials=True)
+    assert relerr(Fm.cpu().numpy(), Fo) < 1e-4 and relerr(Gm.cpu().numpy(), Go) < 1e-4
+
+
+def test_multiscale_jump_after_last_iteration_and_labels(cuda):
+    """diameter=1 recipe of the reference benchmark: the jump lands on the last iteration (pure extrapolation)."""
+    N, M = 2500, 2600
+    x, y = _two_clouds(8, N, M, kind="shifted")
+    x, y = x * 0.5, y * 0.5
+    a, b = np.full(N, 1 / N), np.full(M, 1 / M)
+    kw = dict(p=2, blur=0.05, diameter=1.0, cluster_scale=0.02)
+    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True, **kw)
+    assert info["jumps"][0] == len(info["eps_list"]) - 1
+    xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
+    L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(xt, yt)
+    assert abs(L.item() - ref) / abs(ref) < 1e-4
+    (gx,) = torch.autograd.grad(L, [xt])
+    assert torch.isfinite(gx).all() and gx.abs().max() > 0
+    # user-supplied cluster labels (6-argument call form) reproduce the automatic clustering
+    from geomloss_amd.cluster import grid_cluster
+    lx, ly = grid_cluster(xt.detach(), 0.02), grid_cluster(yt, 0.02)
+    at, bt = torch.full((N,), 1 / N, device=cuda), torch.full((M,), 1 / M, device=cuda)
+    L2 = SamplesLoss("sinkhorn", backend="multiscale", **kw)(lx, at, xt.detach(), ly, bt, yt)
+    assert abs(L2.item() - L.item()) / abs(L.item()) < 1e-5
+
+
+def test_kernel_multiscale_equals_online_up_to_truncation(cuda):
+    N, M = 4000, 4200
+    x, y = _two_clouds(12, N, M, kind="shifted")
+    xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
+    Lo = SamplesLoss("gaussian", blur=0.05, backend="online")(xt, yt)
+    Lm = SamplesLoss("gaussian", blur=0.05, truncate=5, backend="multiscale")(xt, yt)
+    assert abs(Lo.item() - Lm.item()) / abs(Lo.item()) < 1e-4   # exp(-25/2) ~ 4e-6 is what truncation drops
+    (go,) = torch.autograd.grad(Lo, [xt])
+    (gm,) = torch.autograd.grad(Lm, [xt])
+    assert relerr(gm.cpu().numpy(), go.cpu().numpy()) < 1e-3
+    ref = oracle_np.kernel_loss("gaussian", x, y, blur=0.05)
+    assert abs(Lo.item() - ref) / abs(ref) < 1e-4
+
+
+def test_batched_bf16_points_cfg4_shape(cuda):
+    """cfg 4 at reduced B: bf16 points, fp32 dual variables; parity against the fp64 oracle on the
+    bf16-rounded points."""
+    B, N, M = 3, 1024, 1024
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, N, 3, generator=g).to(cuda).bfloat16()
+    y = (torch.rand(B, M, 3, generator=g) * 0.6 + 0.3).to(cuda).bfloat16()
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")(x, y)
+    assert L.shape == (B,) and L.dtype == torch.float32
+    ref = oracle_np.sinkhorn_loss(x.float().cpu().numpy(), y.float().cpu().numpy(), p=2, blur=0.05, diameter=1.8)
+    assert relerr(L.cpu().numpy(), ref) < 1e-4
+
+
+# ---- full-size properties (BASELINE sizes; the oracle cannot run the whole thing) -------------------
+
+@pytest.mark.parametrize("N", [100_000, 1_000_000])
+def test_full_size_softmin_rows_vs_oracle_and_invariances(cuda, N):
+    M = N
+    torch.manual_seed(0)
+    x, y = torch.rand(N, 3, device=cuda), torch.rand(M, 3, device=cuda)
+    eps = 0.05**2
+    h = torch.randn(M, device=cuda) * 3 - float(np.log(M))
+    f = hip.softmin(eps, x, y, h)
+    assert torch.isfinite(f).all()
+    # (a) a random sample of rows against the C oracle (each row is an O(M) CPU job)
+    idx = torch.randint(0, N, (48,), generator=torch.Generator().manual_seed(1))
+    ref = oracle_c.softmin(eps, x[idx.to(cuda)].cpu().numpy(), y.cpu().numpy(), h.cpu().numpy(), 2)
+    assert np.abs(f[idx.to(cuda)].cpu().numpy() - ref).max() < 1.5e-6
+    # (b) shifting the dual vector shifts the result: softmin(h + c) = softmin(h) - eps c
+    f2 = hip.softmin(eps, x, y, h + 2.0)
+    assert (f2 - (f - 2.0 * eps)).abs().max().item() < 1e-6
+    # (c) translating both clouds changes nothing
+    f3 = hip.softmin(eps, x + 10.0, y + 10.0, h)
+    assert (f3 - f).abs().max().item() < 2e-5   # the inputs themselves are rounded at 10 * 2^-24 ~ 6e-7
+    # (d) the direct-difference form agrees with the expanded one
+    f4 = hip.softmin(eps, x, y, h, flags=hip.FLAG_DIRECT)
+    assert (f4 - f).abs().max().item() < 1.5e-6
+
+
+def test_full_size_block_sparse_equals_dense_when_everything_is_kept(cuda):
+    from geomloss_amd.cluster import cluster_ranges_centroids, from_matrix, grid_cluster
+    N = 200_000
+    torch.manual_seed(2)
+    x = torch.rand(N, 3, device=cuda)
+    lab = grid_cluster(x, 0.25)
+    ranges, _, _ = cluster_ranges_centroids(x, lab)
+    xs = x[torch.sort(lab.view(-1))[1]]
+    C = ranges.shape[0]
+    rg = from_matrix(ranges, ranges, torch.ones(C, C, dtype=torch.bool, device=cuda))
+    assert rg.redranges_j.shape[0] == C   # all intervals of a row merge into one
+    h = torch.randn(N, device=cuda)
+    fd = hip.softmin(0.01, xs, xs, h)
+    fs = hip.softmin(0.01, xs, xs, h, ranges=rg)
+    assert (fd - fs).abs().max().item() < 1.5e-6
