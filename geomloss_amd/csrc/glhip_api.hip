@@ -8,6 +8,7 @@
 #include "glhip_generic.h"
 #include "glhip_kconv_ops.h"
 #include "glhip_softmin_ops.h"
+#include "glhip_softmin_mfma.h"
 
 using namespace glhip;
 
@@ -43,10 +44,17 @@ int check_common(const char* fn, const void* x, const void* y, const void* s, in
     return GLHIP_OK;
 }
 
+struct Scratch {
+    void* ws;
+    size_t bytes;
+    bool allow_split;
+};
+
 // rows per thread: 2 keeps the LDS read rate at half a ds_read_b128 per row-column step while leaving
 // enough workgroups to fill 256 CUs; small problems use 1 to expose more workgroups.
-inline bool use_two_rows(int B, int N, int n_ranges) {
+inline bool use_two_rows(int B, int N, int n_ranges, const Scratch& sc) {
     if (n_ranges > 0) return true;
+    if (sc.ws && sc.allow_split) return (long)B * N >= 4 * kBlock;   // column splits provide the parallelism
     const long blocks2 = (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
     return blocks2 >= 1024;
 }
@@ -55,28 +63,54 @@ inline bool use_two_rows(int B, int N, int n_ranges) {
 
 template <int D, int P, bool DIRECT, bool BWD, typename T>
 void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
-                      hipStream_t st) {
-    if (use_two_rows(B, N, n_ranges)) {
-        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, st);
-        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, st);
+                      const Scratch& sc, hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges, sc)) {
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
     } else {
-        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, st);
-        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, st);
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+    }
+}
+
+// p = 2 forward on the matrix cores (glhip_softmin_mfma.h); same partial format / merge kernel as the VALU op
+template <int D, typename T>
+void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                         const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // 256 rows per pass, like the MFMA kernel
+    static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and MFMA kernel must tile rows alike");
+    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
+    const long per_split = (long)B * N * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * 2;
+    if (n_ranges > 0) {
+        hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+    } else {
+        const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+        hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, false>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
 }
 
 template <int D, bool BWD, typename T>
 void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
-                      bool direct, hipStream_t st) {
-    if (p == 1) launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, st);
-    else if (direct) launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, st);
-    else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+                      bool direct, bool mfma, const Scratch& sc, hipStream_t st) {
+    if (p == 1) launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (direct) launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma) launch_softmin_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
 template <bool BWD, typename T>
 int softmin_typed(const void* x, const void* y, const float* h, float* out, const float* fwd, const float* g,
                   float* gx, int B, int N, int M, int D, float eps, int p, const Ranges& rg, int n_ranges,
-                  int flags, hipStream_t st) {
+                  const Scratch& sc, int flags, hipStream_t st) {
     const float s2 = kLog2e / eps;
     const float out_scale = -eps * kLn2;
     if (D <= 3) {
@@ -94,9 +128,10 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.inv_t = 1.0f / prm.t;
         prm.out_scale = out_scale;
         prm.clamp2 = 1e-8f * prm.t * prm.t;
-        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
-        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
-        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, st);
+        const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
+        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
+        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
+        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
     } else {
         if (BWD && D > kGenericMaxGradD)
             return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
@@ -127,22 +162,26 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
 // ---- kernel products ---------------------------------------------------------------------------------
 
 template <int KIND, int D, bool BWD, typename T>
-void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, hipStream_t st) {
-    if (use_two_rows(B, N, n_ranges)) launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, st);
-    else launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, st);
+void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
+                   hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges, sc))
+        launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+    else
+        launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
 }
 
 template <int KIND, bool BWD, typename T>
 void launch_conv_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int D,
-                   hipStream_t st) {
-    if (D == 1) launch_conv_r<KIND, 1, BWD, T>(prm, rg, n_ranges, B, N, M, st);
-    else if (D == 2) launch_conv_r<KIND, 2, BWD, T>(prm, rg, n_ranges, B, N, M, st);
-    else launch_conv_r<KIND, 3, BWD, T>(prm, rg, n_ranges, B, N, M, st);
+                   const Scratch& sc, hipStream_t st) {
+    if (D == 1) launch_conv_r<KIND, 1, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (D == 2) launch_conv_r<KIND, 2, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else launch_conv_r<KIND, 3, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
 template <bool BWD, typename T>
 int conv_typed(int kind, const void* x, const void* y, const float* v, float* out, const float* g, float* gx,
-               int B, int N, int M, int D, float blur, const Ranges& rg, int n_ranges, hipStream_t st) {
+               int B, int N, int M, int D, float blur, const Ranges& rg, int n_ranges, const Scratch& sc,
+               hipStream_t st) {
     if (D <= 3) {
         ConvParams<T> prm;
         prm.x = static_cast<const T*>(x);
@@ -155,17 +194,17 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.t = std::sqrt(0.5f * kLog2e) / blur;
             prm.gscale = -1.0f / (prm.t * blur * blur);
             prm.clamp2 = 0.f;
-            launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+            launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         } else if (kind == GLHIP_LAPLACIAN) {
             prm.t = kLog2e / blur;
             prm.gscale = -1.0f / blur;
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
-            launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+            launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         } else {
             prm.t = 1.0f;
             prm.gscale = -1.0f;
             prm.clamp2 = 1e-8f;
-            launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, st);
+            launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         }
     } else {
         if (BWD && D > kGenericMaxGradD)
@@ -210,11 +249,20 @@ extern "C" {
 
 int glhip_version(void) { return GLHIP_VERSION; }
 
+size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
+    if (B <= 0 || N <= 0 || M <= 0 || D < 1 || D > 3) return 0;   // the generic-D kernels do not split
+    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
+    const int ns = choose_splits(row_blocks, M, n_ranges, 1L << 30);
+    if (ns < 2) return 0;
+    return (size_t)ns * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);   // widest partial: D + 1 floats
+}
+
 const char* glhip_last_error(void) { return g_err; }
 
 int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, int B, int N, int M, int D,
                       float eps, int p, int in_dtype, const int32_t* ranges_i, const int32_t* slices_i,
-                      const int32_t* redranges_j, int n_ranges, int flags, void* stream) {
+                      const int32_t* redranges_j, int n_ranges, void* workspace, size_t workspace_bytes, int flags,
+                      void* stream) {
     int rc = check_common("glhip_softmin_fwd", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
     if (!out) return fail(GLHIP_EINVAL, "glhip_softmin_fwd: NULL out");
@@ -223,16 +271,17 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
     if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
     rc = (in_dtype == GLHIP_F32)
-             ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, flags, st)
-             : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, flags, st);
+             ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
+             : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
     return rc ? rc : check_launch("glhip_softmin_fwd");
 }
 
 int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const float* out, const float* grad_out,
                         float* grad_x, int B, int N, int M, int D, float eps, int p, int in_dtype,
                         const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
-                        int flags, void* stream) {
+                        void* workspace, size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_softmin_bwd_x", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
     if (!out || !grad_out || !grad_x) return fail(GLHIP_EINVAL, "glhip_softmin_bwd_x: NULL out / grad_out / grad_x");
@@ -241,16 +290,17 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const floa
     if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
     rc = (in_dtype == GLHIP_F32)
-             ? softmin_typed<true, float>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, flags, st)
-             : softmin_typed<true, bf16_t>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, flags, st);
+             ? softmin_typed<true, float>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
+             : softmin_typed<true, bf16_t>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
     return rc ? rc : check_launch("glhip_softmin_bwd_x");
 }
 
 int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v, float* out, int B, int N, int M,
                           int D, float blur, int in_dtype, const int32_t* ranges_i, const int32_t* slices_i,
-                          const int32_t* redranges_j, int n_ranges, int flags, void* stream) {
-    (void)flags;
+                          const int32_t* redranges_j, int n_ranges, void* workspace, size_t workspace_bytes,
+                          int flags, void* stream) {
     int rc = check_common("glhip_kernel_conv_fwd", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
     if (!out) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: NULL out");
@@ -259,17 +309,17 @@ int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v
     if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
     rc = (in_dtype == GLHIP_F32)
-             ? conv_typed<false, float>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, st)
-             : conv_typed<false, bf16_t>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, st);
+             ? conv_typed<false, float>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, st)
+             : conv_typed<false, bf16_t>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, st);
     return rc ? rc : check_launch("glhip_kernel_conv_fwd");
 }
 
 int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float* v, const float* g, float* grad_x,
                             int B, int N, int M, int D, float blur, int in_dtype, const int32_t* ranges_i,
-                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, int flags,
-                            void* stream) {
-    (void)flags;
+                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                            size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_kernel_conv_bwd_x", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
     if (!g || !grad_x) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: NULL g / grad_x");
@@ -278,9 +328,10 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
     if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
     rc = (in_dtype == GLHIP_F32)
-             ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, st)
-             : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, st);
+             ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, st)
+             : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, st);
     return rc ? rc : check_launch("glhip_kernel_conv_bwd_x");
 }
 

@@ -137,6 +137,30 @@ struct ConvOp {
             }
         }
     }
+
+    // column splits: plain partial sums
+    static constexpr int kPartial = BWD ? D_ : 1;
+    static __device__ __forceinline__ void store_partial(const RowState& st, int r, float* dst) {
+#pragma unroll
+        for (int d = 0; d < kPartial; ++d) dst[d] = st.acc[r][d];
+    }
+    static __device__ __forceinline__ void merge_row(const Params& p, int b, int N, int i, const float (&)[D_],
+                                                     const float* part, int ns, long stride) {
+        float acc[kPartial];
+#pragma unroll
+        for (int d = 0; d < kPartial; ++d) acc[d] = 0.f;
+        for (int k = 0; k < ns; ++k) {
+#pragma unroll
+            for (int d = 0; d < kPartial; ++d) acc[d] += part[k * stride + d];
+        }
+        if (!BWD) {
+            p.out[(long)b * N + i] = acc[0];
+        } else {
+            const float gi = p.g[(long)b * N + i] * p.gscale;
+#pragma unroll
+            for (int d = 0; d < D_; ++d) p.gx[((long)b * N + i) * D_ + d] = gi * acc[d];
+        }
+    }
 };
 
 }  // namespace glhip

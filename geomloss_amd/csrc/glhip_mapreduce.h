@@ -1,5 +1,5 @@
-// glhip_mapreduce.h — the one tiling skeleton shared by every low-dimensional (D <= 3)
-// reduction of this library:  out_i = REDUCE_j F(x_i, y_j, s_j).
+// glhip_mapreduce.h — the tiling skeleton shared by the low-dimensional (D <= 3) reductions
+//   out_i = REDUCE_j F(x_i, y_j, s_j).
 //
 // Work decomposition (CDNA4):
 //   * one workgroup = 256 threads = 4 wavefronts; each thread owns R rows i, held in VGPRs;
@@ -7,32 +7,36 @@
 //   * the column cloud is streamed through LDS in tiles of kTile records of 16 B
 //     ({y_0, y_1, y_2, s_j}); every lane of a wavefront reads the same record at the same time,
 //     i.e. one conflict-free broadcast ds_read_b128 per column and per R rows.
-//   * dense mode: grid.x tiles the rows, grid.y = batch.  Block-sparse mode: grid.x = row block k of
-//     the KeOps-style ranges; the workgroup walks the column intervals of its CSR slice.
-//   * coordinates are re-centred on the first row of the workgroup before any product is formed,
-//     so the expanded form  -|x-y|^2/2 = x.y - |x|^2/2 - |y|^2/2  is evaluated on offsets that are
-//     at most one cloud diameter long (and much shorter when the rows are cluster-sorted).
+//   * grid = (row blocks) x (batch) x (column splits).  A workgroup that owns all the columns of its
+//     rows writes the final result; otherwise it writes a per-row partial state to the caller's
+//     workspace and `merge_kernel` combines the splits.  Column splits exist for load balance: one
+//     workgroup working through 1e6 columns runs for ~the whole kernel, so without them the last
+//     partially filled round of workgroups leaves most CUs idle (measured: 4.2 of 7 resident waves/SIMD).
+//   * dense mode: grid.x tiles the rows.  Block-sparse mode: grid.x = row block k of the KeOps-style
+//     ranges; split s of a row block takes the column intervals q = s (mod n_splits) of its CSR slice.
+//   * coordinates are re-centred on the first row of the workgroup's row pass before any product is
+//     formed, so the expanded form  -|x-y|^2/2 = x.y - |x|^2/2 - |y|^2/2  is evaluated on offsets that
+//     are at most one cloud diameter long (and much shorter when the rows are cluster-sorted).
 //
-// An `Op` supplies: Params, RowState, kRows (R), kDim (D), and the device functions
-//   init_rows / make_record / neutral_record / consume / finish_rows.
+// An `Op` supplies: Params, RowState, kRows (R), kDim (D), kPartial and the device functions
+//   load_centre / init_rows / make_record / neutral_record / consume / finish_rows /
+//   store_partial / merge_row.
 #pragma once
 
 #include "glhip_common.h"
 
 namespace glhip {
 
-template <class Op, bool SPARSE>
-__global__ void __launch_bounds__(kBlock)
-mapreduce_kernel(typename Op::Params prm, Ranges rg, int N, int M) {
-    constexpr int D = Op::kDim;
-    constexpr int R = Op::kRows;
-    constexpr int kRowsPerPass = kBlock * R;
-    __shared__ Rec<D> tile[kTile];
+struct SplitInfo {
+    int n_splits;       // 1 = no split
+    float* workspace;   // [n_splits][B*N][kPartial] floats
+    long split_stride;  // floats between consecutive splits = B*N*kPartial
+};
 
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-
-    int row_begin, row_end, q_begin, q_end;
+// rows [row_begin,row_end) and CSR slice [q_begin,q_end) of workgroup blockIdx.x
+template <bool SPARSE>
+__device__ __forceinline__ void block_extent(const Ranges& rg, int N, int rows_per_pass, int& row_begin,
+                                             int& row_end, int& q_begin, int& q_end) {
     if (SPARSE) {
         const int k = blockIdx.x;
         row_begin = rg.ranges_i[2 * k];
@@ -40,50 +44,131 @@ mapreduce_kernel(typename Op::Params prm, Ranges rg, int N, int M) {
         q_begin = (k == 0) ? 0 : rg.slices_i[k - 1];
         q_end = rg.slices_i[k];
     } else {
-        row_begin = blockIdx.x * kRowsPerPass;
-        row_end = min(N, row_begin + kRowsPerPass);
+        row_begin = blockIdx.x * rows_per_pass;
+        row_end = min(N, row_begin + rows_per_pass);
         q_begin = 0;
         q_end = 1;
     }
+}
+
+// column interval q as seen by split `s` of `ns`
+template <bool SPARSE>
+__device__ __forceinline__ void column_interval(const Ranges& rg, int M, int q, int s, int ns, int& js, int& je) {
+    if (SPARSE) {
+        js = rg.redranges_j[2 * q];
+        je = rg.redranges_j[2 * q + 1];
+    } else {
+        const int len = (((M + ns - 1) / ns) + kChunk - 1) & ~(kChunk - 1);
+        js = min(M, s * len);
+        je = min(M, js + len);
+    }
+}
+
+template <class Op, bool SPARSE>
+__global__ void __launch_bounds__(kBlock)
+mapreduce_kernel(typename Op::Params prm, Ranges rg, int N, int M, SplitInfo sp) {
+    constexpr int D = Op::kDim;
+    constexpr int R = Op::kRows;
+    constexpr int kRowsPerPass = kBlock * R;
+    __shared__ Rec<D> tile[kTile];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int split = blockIdx.z;
+    const int ns = sp.n_splits;
+
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<SPARSE>(rg, N, kRowsPerPass, row_begin, row_end, q_begin, q_end);
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerPass) {
-        // centre of this pass: its first row (wave-uniform, read through the scalar path)
         float centre[D];
-        Op::load_centre(prm, b, N, row0, centre);
+        Op::load_centre(prm, b, N, row0, centre);   // wave-uniform (scalar loads)
 
         typename Op::RowState st;
         Op::init_rows(prm, b, N, row0, row_end, tid, centre, st);
 
-        for (int q = q_begin; q < q_end; ++q) {
-            const int js = SPARSE ? rg.redranges_j[2 * q] : 0;
-            const int je = SPARSE ? rg.redranges_j[2 * q + 1] : M;
+        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
+            int js, je;
+            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
             for (int j0 = js; j0 < je; j0 += kTile) {
                 const int n = min(kTile, je - j0);
                 const int npad = (n + kChunk - 1) & ~(kChunk - 1);
                 __syncthreads();   // previous tile fully consumed
                 for (int t = tid; t < npad; t += kBlock) {
-                    tile[t] = (t < n) ? Op::make_record(prm, b, M, j0 + t, centre)
-                                      : Op::neutral_record();
+                    tile[t] = (t < n) ? Op::make_record(prm, b, M, j0 + t, centre) : Op::neutral_record();
                 }
                 __syncthreads();
                 for (int jj = 0; jj < npad; jj += kChunk) Op::consume(st, &tile[jj]);
             }
         }
-        Op::finish_rows(prm, b, N, row0, row_end, tid, centre, st);
+        if (ns == 1) {
+            Op::finish_rows(prm, b, N, row0, row_end, tid, centre, st);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = row0 + r * kBlock + tid;
+                if (i < row_end)
+                    Op::store_partial(st, r, sp.workspace + split * sp.split_stride +
+                                                 ((long)b * N + i) * Op::kPartial);
+            }
+        }
     }
 }
 
-// Host-side launch helper.
+// Combines the column splits of every row: one thread per row.
+template <class Op, bool SPARSE>
+__global__ void __launch_bounds__(kBlock)
+merge_kernel(typename Op::Params prm, Ranges rg, int N, SplitInfo sp) {
+    constexpr int D = Op::kDim;
+    constexpr int kRowsPerPass = kBlock * Op::kRows;
+    const int b = blockIdx.y;
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<SPARSE>(rg, N, kRowsPerPass, row_begin, row_end, q_begin, q_end);
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerPass) {
+        float centre[D];
+        Op::load_centre(prm, b, N, row0, centre);
+        for (int i = row0 + threadIdx.x; i < min(row_end, row0 + kRowsPerPass); i += kBlock) {
+            Op::merge_row(prm, b, N, i, centre, sp.workspace + ((long)b * N + i) * Op::kPartial, sp.n_splits,
+                          sp.split_stride);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+
+// Number of column splits: enough workgroups for >= ~16 rounds over the chip.
+static inline int choose_splits(long row_blocks, int M, int n_ranges, long max_by_workspace) {
+    const long target = 256L * 8 * 16;
+    long ns = (target + row_blocks - 1) / row_blocks;
+    const long by_cols = (n_ranges > 0) ? 8 : (long)M / 512;   // at least 512 columns per split
+    ns = ns < by_cols ? ns : by_cols;
+    ns = ns < 32 ? ns : 32;
+    ns = ns < max_by_workspace ? ns : max_by_workspace;
+    return ns < 1 ? 1 : (int)ns;
+}
+
 template <class Op>
-static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges& rg, int n_ranges,
-                                    int B, int N, int M, hipStream_t stream) {
+static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges& rg, int n_ranges, int B, int N,
+                                    int M, void* workspace, size_t workspace_bytes, bool allow_split,
+                                    hipStream_t stream) {
+    const int rows_per_block = kBlock * Op::kRows;
+    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + rows_per_block - 1) / rows_per_block);
+    const long per_split = (long)B * N * Op::kPartial * sizeof(float);
+    const long fit = (workspace && per_split > 0) ? (long)(workspace_bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(workspace);
+    sp.split_stride = (long)B * N * Op::kPartial;
     if (n_ranges > 0) {
-        dim3 grid(n_ranges, 1, 1);
-        hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rg, N, M);
+        dim3 grid(n_ranges, 1, sp.n_splits);
+        hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<Op, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, stream, prm, rg, N, sp);
     } else {
-        const int rows_per_block = kBlock * Op::kRows;
-        dim3 grid((N + rows_per_block - 1) / rows_per_block, B, 1);
-        hipLaunchKernelGGL((mapreduce_kernel<Op, false>), grid, dim3(kBlock), 0, stream, prm, rg, N, M);
+        dim3 grid((N + rows_per_block - 1) / rows_per_block, B, sp.n_splits);
+        hipLaunchKernelGGL((mapreduce_kernel<Op, false>), grid, dim3(kBlock), 0, stream, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<Op, false>), dim3(grid.x, B, 1), dim3(kBlock), 0, stream, prm, rg, N, sp);
     }
 }
 

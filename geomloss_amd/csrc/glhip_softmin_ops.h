@@ -179,6 +179,24 @@ struct SoftminFwdOp {
             }
         }
     }
+
+    // column splits: partial state of a row = (max exponent, sum of 2^(u - max)); both centre-independent
+    static constexpr int kPartial = 2;
+    static __device__ __forceinline__ void store_partial(const RowState& st, int r, float* dst) {
+        dst[0] = st.r[r] + st.m[r];
+        dst[1] = st.s[r];
+    }
+    static __device__ __forceinline__ void merge_row(const Params& p, int b, int N, int i, const float (&)[D_],
+                                                     const float* part, int ns, long stride) {
+        float m = kNegBig, s = 0.f;
+        for (int k = 0; k < ns; ++k) {
+            const float mk = part[k * stride], sk = part[k * stride + 1];
+            const float mn = fmaxf(m, mk);
+            s = s * fast_exp2(m - mn) + sk * fast_exp2(mk - mn);
+            m = mn;
+        }
+        p.out[(long)b * N + i] = p.out_scale * (m + fast_log2(s));
+    }
 };
 
 // ---- backward with respect to x ------------------------------------------------------------------
@@ -283,6 +301,36 @@ struct SoftminBwdOp {
                     p.gx[((long)b * N + i) * D_ + d] = gi * v;
                 }
             }
+        }
+    }
+
+    // column splits: partial sums (acc[D], sw) are additive; all splits of a row pass share its centre
+    static constexpr int kPartial = D_ + 1;
+    static __device__ __forceinline__ void store_partial(const RowState& st, int r, float* dst) {
+#pragma unroll
+        for (int d = 0; d < D_; ++d) dst[d] = st.acc[r][d];
+        dst[D_] = st.sw[r];
+    }
+    static __device__ __forceinline__ void merge_row(const Params& p, int b, int N, int i, const float (&c)[D_],
+                                                     const float* part, int ns, long stride) {
+        float acc[D_], sw = 0.f;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) acc[d] = 0.f;
+        for (int k = 0; k < ns; ++k) {
+#pragma unroll
+            for (int d = 0; d < D_; ++d) acc[d] += part[k * stride + d];
+            sw += part[k * stride + D_];
+        }
+        float xi[D_];
+        load_point<D_, T>(p.x, (long)b * N + i, xi);
+        const float gi = p.g[(long)b * N + i];
+        const float inv = (sw > 0.f) ? 1.0f / sw : 0.f;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) {
+            float v;
+            if (P == 2) v = (xi[d] - c[d]) - acc[d] * inv * (DIRECT ? p.inv_t : 1.0f);
+            else v = acc[d] * inv;
+            p.gx[((long)b * N + i) * D_ + d] = gi * v;
         }
     }
 };

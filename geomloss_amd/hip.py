@@ -19,22 +19,24 @@ LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
 GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
-FLAG_DIRECT = 1
+FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT = 1, 2, 4
 
 # every symbol include/glhip.h declares, with its ctypes signature
-_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 _RANGES = [_vp, _vp, _vp, _c_int]
+_TAIL = [_vp, _c_size, _c_int, _vp]  # workspace, workspace_bytes, flags, stream
 SIGNATURES = {
     "glhip_version": (_c_int, []),
     "glhip_last_error": (ctypes.c_char_p, []),
+    "glhip_workspace_bytes": (_c_size, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "glhip_softmin_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int]
-                          + _RANGES + [_c_int, _vp]),
+                          + _RANGES + _TAIL),
     "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
-                                     _c_int] + _RANGES + [_c_int, _vp]),
+                                     _c_int] + _RANGES + _TAIL),
     "glhip_kernel_conv_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int]
-                              + _RANGES + [_c_int, _vp]),
+                              + _RANGES + _TAIL),
     "glhip_kernel_conv_bwd_x": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
-                                         _c_int] + _RANGES + [_c_int, _vp]),
+                                         _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
 }
 
@@ -131,6 +133,16 @@ def _range_args(ranges, B):
     return ranges.c_args()
 
 
+def _workspace(lib, x, B, N, M, D, ranges):
+    """Scratch buffer for column splits (torch's caching allocator makes this a free-list lookup)."""
+    n_ranges = 0 if ranges is None else int(ranges.ranges_i.shape[0])
+    nbytes = int(lib.glhip_workspace_bytes(B, N, M, D, n_ranges))
+    if nbytes == 0:
+        return None, [None, 0]
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    return ws, [ctypes.c_void_p(ws.data_ptr()), nbytes]
+
+
 def _as_batched(x, y, s):
     """(N,D),(M,D),(M,) -> (1,N,D),(1,M,D),(1,M); batched inputs pass through."""
     if x.dim() == 2:
@@ -149,8 +161,10 @@ def softmin_fwd_raw(x, y, h, eps, p=2, ranges=None, flags=0):
     M = y.shape[1]
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
         rc = lib.glhip_softmin_fwd(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, D,
-                                   float(eps), int(p), _dtype_code(x), *_range_args(ranges, B), int(flags), _stream(x))
+                                   float(eps), int(p), _dtype_code(x), *_range_args(ranges, B), *ws_args,
+                                   int(flags), _stream(x))
     _check(rc, lib)
     return out
 
@@ -161,34 +175,38 @@ def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
     M = y.shape[1]
     gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
         rc = lib.glhip_softmin_bwd_x(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), grad_out.data_ptr(),
                                      gx.data_ptr(), B, N, M, D, float(eps), int(p), _dtype_code(x),
-                                     *_range_args(ranges, B), int(flags), _stream(x))
+                                     *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
     _check(rc, lib)
     return gx
 
 
-def kernel_conv_fwd_raw(kind, x, y, v, blur, ranges=None):
+def kernel_conv_fwd_raw(kind, x, y, v, blur, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
         rc = lib.glhip_kernel_conv_fwd(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), out.data_ptr(), B, N, M, D,
-                                       float(blur), _dtype_code(x), *_range_args(ranges, B), 0, _stream(x))
+                                       float(blur), _dtype_code(x), *_range_args(ranges, B), *ws_args, int(flags),
+                                       _stream(x))
     _check(rc, lib)
     return out
 
 
-def kernel_conv_bwd_x_raw(kind, x, y, v, g, blur, ranges=None):
+def kernel_conv_bwd_x_raw(kind, x, y, v, g, blur, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
     gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
         rc = lib.glhip_kernel_conv_bwd_x(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(),
                                          gx.data_ptr(), B, N, M, D, float(blur), _dtype_code(x),
-                                         *_range_args(ranges, B), 0, _stream(x))
+                                         *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
     _check(rc, lib)
     return gx
 

@@ -37,13 +37,14 @@
 #ifndef GLHIP_H
 #define GLHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 100 /* 0.1.0 */
+#define GLHIP_VERSION 101 /* 0.1.1 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -55,8 +56,10 @@ extern "C" {
 #define GLHIP_ENERGY 2    /* k = -|x-y|  (blur ignored)      kernel_samples.py:80-82 */
 
 /* flags (bitmask) */
-#define GLHIP_FLAG_DIRECT 1 /* p=2 softmin: evaluate |x-y|^2 as sum (x_d-y_d)^2 (KeOps' SqDist)
-                               instead of the per-workgroup-centred expansion. Slower, tighter. */
+#define GLHIP_FLAG_DIRECT 1   /* p=2 softmin: evaluate |x-y|^2 as sum (x_d-y_d)^2 (KeOps' SqDist)
+                                 instead of the per-workgroup-centred expansion. Slower, tighter. */
+#define GLHIP_FLAG_NO_MFMA 2  /* p=2 softmin forward: form the exponents on the VALU instead of the matrix cores */
+#define GLHIP_FLAG_NO_SPLIT 4 /* never split the columns of a row over several workgroups (ignore the workspace) */
 
 /* error codes */
 #define GLHIP_OK 0
@@ -66,6 +69,16 @@ extern "C" {
 
 int glhip_version(void);
 const char* glhip_last_error(void);
+
+/*
+ * Scratch memory.  Every reduction below accepts an optional caller-owned device buffer
+ * (`workspace`, `workspace_bytes`; NULL / 0 is always valid).  With it, the columns of a row may be
+ * split over several workgroups (load balance on 256 CUs) and merged by a second small kernel on the
+ * same stream.  glhip_workspace_bytes returns a size that lets every entry point use its preferred
+ * split for the given problem; smaller buffers are used as far as they go.  The buffer must stay
+ * alive until the work queued on `stream` has run; its contents are scratch.
+ */
+size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges);
 
 /*
  * Soft-C-transform  out[b,i] = -eps * log sum_j exp( h[b,j] - C(x[b,i], y[b,j]) / eps ),
@@ -83,7 +96,7 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
                       int B, int N, int M, int D, float eps, int p, int in_dtype,
                       const int32_t* ranges_i, const int32_t* slices_i,
                       const int32_t* redranges_j, int n_ranges,
-                      int flags, void* stream);
+                      void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Gradient of the above with respect to x (the only differentiable argument on the
@@ -100,7 +113,7 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h,
                         int B, int N, int M, int D, float eps, int p, int in_dtype,
                         const int32_t* ranges_i, const int32_t* slices_i,
                         const int32_t* redranges_j, int n_ranges,
-                        int flags, void* stream);
+                        void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Kernel-matrix × vector product  out[b,i] = sum_j k(x[b,i], y[b,j]) * v[b,j].
@@ -116,7 +129,7 @@ int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v
                           int B, int N, int M, int D, float blur, int in_dtype,
                           const int32_t* ranges_i, const int32_t* slices_i,
                           const int32_t* redranges_j, int n_ranges,
-                          int flags, void* stream);
+                          void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Gradient of sum_i g_i * out_i (out from glhip_kernel_conv_fwd) with respect to x:
@@ -132,7 +145,7 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
                             int B, int N, int M, int D, float blur, int in_dtype,
                             const int32_t* ranges_i, const int32_t* slices_i,
                             const int32_t* redranges_j, int n_ranges,
-                            int flags, void* stream);
+                            void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Row-wise soft-min of an explicit (B,N,M) fp32 cost matrix:

@@ -35,7 +35,10 @@ def main():
         what = args.what.split(",")
         res = {}
         if "softmin" in what:
-            res["softmin p2"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
+            res["softmin p2 (mfma+split)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
+            res["softmin p2 mfma nosplit"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=4))
+            res["softmin p2 valu split"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=2))
+            res["softmin p2 valu nosplit"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=6))
         if "softmin_direct" in what:
             res["softmin p2 direct"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=1))
         if "softmin_p1" in what:
@@ -49,7 +52,7 @@ def main():
             if nm in what:
                 res["conv " + nm] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05))
         for k, (tmin, tmed) in res.items():
-            print(f"N=M={N:>8d} {k:20s} min {tmin*1e3:10.3f} ms  med {tmed*1e3:10.3f} ms  {pairs/tmin:.3e} pairs/s")
+            print(f"N=M={N:>8d} {k:26s} min {tmin*1e3:10.3f} ms  med {tmed*1e3:10.3f} ms  {pairs/tmin:.3e} pairs/s")
 
 
 if __name__ == "__main__":
