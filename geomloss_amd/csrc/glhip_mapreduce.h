@@ -138,7 +138,7 @@ merge_kernel(typename Op::Params prm, Ranges rg, int N, SplitInfo sp) {
 
 // Number of column splits: enough workgroups for >= ~16 rounds over the chip.
 static inline int choose_splits(long row_blocks, int M, int n_ranges, long max_by_workspace) {
-    const long target = 256L * 8 * 16;
+    const long target = 256L * 4 * 10;   // ~10 rounds of 4 workgroups per CU
     long ns = (target + row_blocks - 1) / row_blocks;
     const long by_cols = (n_ranges > 0) ? 8 : (long)M / 512;   // at least 512 columns per split
     ns = ns < by_cols ? ns : by_cols;

@@ -7,7 +7,7 @@
 // "subtract the running max" (it becomes the C operand of the MFMA) off the VALU leaves it with only
 // exp2 / add / max per pair: 6.6 -> ~2.6 VALU instructions per pair.
 //
-// Layout (one wavefront = kMfmaRT row tiles of 16 rows; 4 wavefronts per workgroup = 256 rows):
+// Layout (one wavefront = RT row tiles of 16 rows; 4 wavefronts per workgroup = 64*RT rows):
 //   A operand, per row tile: lane l holds A[i = l%16][k = l/16] = (a_i0 | a_i1 | a_i2 | 1)[k].
 //   B operand: lane l holds B[k = l/16][j = l%16].  The LDS tile stores, per super-group of 64 columns,
 //     one float4 per lane whose component g is the operand of column group g (16 columns); one
@@ -15,11 +15,12 @@
 //   D: lane l, register r  <->  row 4*(l/16) + r, column l%16 of the group.  So each lane keeps the running
 //     (max, sum) of 4 rows over its own 1/16th of the columns; nothing crosses lanes until the final
 //     16-lane butterfly merge.
-// The running max is lazy: C = -m is only refreshed when a row sum passes kSumThr = 2^100 (a term at least
-// 2^84 above m arrived, or overflowed to +inf); the row tile is then recomputed exactly from the OLD sums
-// with C = 0 and m := max(m, new exponents).  So m <= true max always, sums never overflow, and no per-pair
-// max instruction is issued.  The first super-group triggers that path by construction (m starts at -3e38),
-// which is also the exact initialisation.
+// The running max is lazy.  The first 64 columns initialise m_i exactly (max over the 64 columns, shared by
+// the 16 lanes of the row).  After that a whole LDS tile (1024 columns) is accumulated speculatively with
+// C = -m and NO per-pair max / compare at all; only at the end of the tile the tile sums are checked: if
+// one passed kSumThr = 2^100 (a term ~2^80 above m arrived, or overflowed to +inf / NaN) the tile is redone
+// from the untouched old sums with exact per-group maxima (C = 0).  m <= true max always, nothing can
+// overflow unnoticed, and the hot loop is branch-free so the compiler can pipeline across column groups.
 #pragma once
 
 #include "glhip_mapreduce.h"
@@ -29,7 +30,7 @@ namespace glhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaRT = 4;                            // 16-row tiles per wavefront
+constexpr int kMfmaRT = 4;                            // 16-row tiles per wavefront (weighted-sum kernels)
 constexpr int kMfmaRowsPerWave = kMfmaRT * 16;        // 64
 constexpr int kMfmaRowsPerBlock = 4 * kMfmaRowsPerWave;   // 256
 constexpr float kSumThr = 1.2676506e30f;            // 2^100: refresh the lazy max when a row sum passes it
@@ -45,9 +46,11 @@ __device__ __forceinline__ f32x4 maxv(f32x4 a, f32x4 b) {
     return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
 }
 
-template <int D, typename T, bool SPARSE>
+template <int D, typename T, bool SPARSE, int RT = kMfmaRT>
 __global__ void __launch_bounds__(kBlock)
 softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    constexpr int kRowsPerWave = RT * 16;
+    constexpr int kRowsPerBlock = 4 * kRowsPerWave;
     __shared__ f32x4 tileB[kTile];   // [super-group][lane] -> 4 column groups
 
     const int tid = threadIdx.x;
@@ -60,29 +63,31 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
     const int lj = lane & 15;
 
     int row_begin, row_end, q_begin, q_end;
-    block_extent<SPARSE>(rg, N, kMfmaRowsPerBlock, row_begin, row_end, q_begin, q_end);
+    block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end);
 
-    for (int row0 = row_begin; row0 < row_end; row0 += kMfmaRowsPerBlock) {
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
         load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
         // A operands of this wavefront's row tiles
-        const int wave_row0 = row0 + wave * kMfmaRowsPerWave;
-        float A[kMfmaRT];
+        const int wave_row0 = row0 + wave * kRowsPerWave;
+        float A[RT];
 #pragma unroll
-        for (int rt = 0; rt < kMfmaRT; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             const int i = min(wave_row0 + rt * 16 + lj, row_end - 1);
             float v = (lk == 3) ? 1.0f : 0.0f;
             if (lk < D) v = (to_f32<T>(prm.x[((long)b * N + i) * D + lk]) - centre[lk < D ? lk : 0]) * prm.s2;
             A[rt] = v;
         }
-        f32x4 negm[kMfmaRT], ssum[kMfmaRT];
+        f32x4 negm[RT], ssum[RT];
 #pragma unroll
-        for (int rt = 0; rt < kMfmaRT; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             negm[rt] = f32x4{-kMinusHuge, -kMinusHuge, -kMinusHuge, -kMinusHuge};
             ssum[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const bool wave_active = wave_row0 < row_end;
+        bool first_group = true;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
         for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
             int js, je;
@@ -113,26 +118,54 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
                 __syncthreads();
                 if (!wave_active) continue;
 
-                for (int G = 0; G < npad / 64; ++G) {
-                    const f32x4 B4 = tileB[G * 64 + lane];
-                    // speculative pass: every row tile against the lazy maxima
-                    f32x4 snew[kMfmaRT];
-                    float smax = 0.f;
+                const int nG = npad / 64;
+                int G0 = 0;
+                if (first_group) {
+                    // exact initialisation on the first 64 columns; the max is shared by the 16 lanes of a row
+                    const f32x4 B4 = tileB[lane];
 #pragma unroll
-                    for (int rt = 0; rt < kMfmaRT; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 u0 = mfma4(A[rt], B4.x, zero), u1 = mfma4(A[rt], B4.y, zero);
+                        const f32x4 u2 = mfma4(A[rt], B4.z, zero), u3 = mfma4(A[rt], B4.w, zero);
+                        f32x4 um = maxv(maxv(u0, u1), maxv(u2, u3));
+#pragma unroll
+                        for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) um[r] = fmaxf(um[r], __shfl_xor(um[r], off, 64));
+                        }
+                        um = maxv(um, f32x4{kMinusHuge, kMinusHuge, kMinusHuge, kMinusHuge});   // -inf columns only
+                        negm[rt] = -um;
+                        ssum[rt] = (exp2v(u0 - um) + exp2v(u1 - um)) + (exp2v(u2 - um) + exp2v(u3 - um));
+                    }
+                    first_group = false;
+                    G0 = 1;
+                }
+
+                // speculative, branch-free pass over the tile
+                f32x4 stmp[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) stmp[rt] = zero;
+                for (int G = G0; G < nG; ++G) {
+                    const f32x4 B4 = tileB[G * 64 + lane];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
                         const f32x4 d0 = mfma4(A[rt], B4.x, negm[rt]);
                         const f32x4 d1 = mfma4(A[rt], B4.y, negm[rt]);
                         const f32x4 d2 = mfma4(A[rt], B4.z, negm[rt]);
                         const f32x4 d3 = mfma4(A[rt], B4.w, negm[rt]);
-                        snew[rt] = ssum[rt] + ((exp2v(d0) + exp2v(d1)) + (exp2v(d2) + exp2v(d3)));
-                        smax = fmaxf(fmaxf(smax, snew[rt].x), fmaxf(fmaxf(snew[rt].y, snew[rt].z), snew[rt].w));
+                        stmp[rt] += (exp2v(d0) + exp2v(d1)) + (exp2v(d2) + exp2v(d3));
                     }
-                    if (__any(!(smax < kSumThr))) {
-                        // some exponent ran far above a lazy max (or this is the first super-group): redo the
-                        // super-group exactly from the OLD sums, with C = 0 and refreshed maxima
+                }
+                float smax = 0.f;
 #pragma unroll
-                        for (int rt = 0; rt < kMfmaRT; ++rt) {
-                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                for (int rt = 0; rt < RT; ++rt)
+                    smax = fmaxf(fmaxf(smax, stmp[rt].x), fmaxf(fmaxf(stmp[rt].y, stmp[rt].z), stmp[rt].w));
+                if (__any(!(smax < kSumThr))) {
+                    // redo the tile from the old sums with exact per-group maxima
+                    for (int G = G0; G < nG; ++G) {
+                        const f32x4 B4 = tileB[G * 64 + lane];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
                             const f32x4 u0 = mfma4(A[rt], B4.x, zero), u1 = mfma4(A[rt], B4.y, zero);
                             const f32x4 u2 = mfma4(A[rt], B4.z, zero), u3 = mfma4(A[rt], B4.w, zero);
                             const f32x4 mold = -negm[rt];
@@ -141,10 +174,10 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
                             ssum[rt] = ssum[rt] * exp2v(mold - mnew) +
                                        ((exp2v(u0 - mnew) + exp2v(u1 - mnew)) + (exp2v(u2 - mnew) + exp2v(u3 - mnew)));
                         }
-                    } else {
-#pragma unroll
-                        for (int rt = 0; rt < kMfmaRT; ++rt) ssum[rt] = snew[rt];
                     }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
                 }
             }
         }
@@ -152,7 +185,7 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
         if (wave_active) {
             // merge the 16 column-lanes of every row, then lane (l%16 == r) finishes row 4*(l/16) + r
 #pragma unroll
-            for (int rt = 0; rt < kMfmaRT; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 f32x4 m = -negm[rt], s = ssum[rt];
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) {

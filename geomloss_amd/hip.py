@@ -252,44 +252,48 @@ class _Softmin(torch.autograd.Function):
         return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None
 
 
+# kernel-selection knobs for A/B runs (tuning through the environment only): a GLHIP_FLAG_* bitmask
+ENV_FLAGS = int(os.environ.get("GEOMLOSS_HIP_FLAGS", "0"))
+
+
 def softmin(eps, x, y, h, p=2, ranges=None, flags=0):
     """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32."""
-    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags))
+    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS)
 
 
 class _KernelConv(torch.autograd.Function):
     """out_i = sum_j k(x_i,y_j) v_j, differentiable in x, y and v."""
 
     @staticmethod
-    def forward(ctx, kind, x, y, v, blur, ranges):
+    def forward(ctx, kind, x, y, v, blur, ranges, flags):
         xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        out = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges)
+        out = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, flags)
         ctx.save_for_backward(xb, yb, vb)
-        ctx.cfg = (kind, blur, ranges, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
+        ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
         return out if batched else out.view(-1)
 
     @staticmethod
     def backward(ctx, grad_out):
         xb, yb, vb = ctx.saved_tensors
-        kind, blur, ranges, xs, ys, vs, xdt, ydt, vdt = ctx.cfg
+        kind, blur, ranges, flags, xs, ys, vs, xdt, ydt, vdt = ctx.cfg
         g = grad_out.reshape(xb.shape[0], -1).float().contiguous()
         rt = None if ranges is None else ranges.t()
         gx = gy = gv = None
         if ctx.needs_input_grad[1]:
-            gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges).reshape(xs).to(xdt)
+            gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges, flags).reshape(xs).to(xdt)
         if ctx.needs_input_grad[2]:
-            gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt).reshape(ys).to(ydt)
+            gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt, flags).reshape(ys).to(ydt)
         if ctx.needs_input_grad[3]:
-            gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt).reshape(vs).to(vdt)
-        return None, gx, gy, gv, None, None
+            gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt, flags).reshape(vs).to(vdt)
+        return None, gx, gy, gv, None, None, None
 
 
-def kernel_conv(kind, x, y, v, blur=0.05, ranges=None):
+def kernel_conv(kind, x, y, v, blur=0.05, ranges=None, flags=0):
     """Kernel-matrix x vector product on the GPU; ``kind`` is a name or a GLHIP_* code."""
     kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
-    return _KernelConv.apply(kind, x, y, v, 1.0 if blur is None else float(blur), ranges)
+    return _KernelConv.apply(kind, x, y, v, 1.0 if blur is None else float(blur), ranges, int(flags) | ENV_FLAGS)
 
 
 class _SoftminDense(torch.autograd.Function):

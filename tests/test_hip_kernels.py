@@ -58,10 +58,12 @@ def test_softmin_bwd_vs_oracle(cuda, N, M, D, p):
     x, y, h = _clouds(7 * N + D, N, M, D)
     g = np.random.default_rng(3).standard_normal(N).astype(np.float32)
     ref = oracle_c.softmin_grad_x(eps, x, y, h, g, p)
-    xt = _t(x, cuda).requires_grad_(True)
-    out = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=p)
-    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
-    assert relerr(gx.cpu().numpy(), ref) < 2e-5   # fp32 weights 2^(u - lse): exponent error ~1e-5 at eps = 0.01
+    for flags in (0, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_DIRECT):
+        xt = _t(x, cuda).requires_grad_(True)
+        out = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=p, flags=flags)
+        (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
+        # fp32 weights 2^(u - lse): exponent error ~1e-5 at eps = 0.01 in the expanded forms
+        assert relerr(gx.cpu().numpy(), ref) < 2e-5, flags
 
 
 def test_softmin_batched_and_bf16(cuda):
@@ -101,7 +103,8 @@ def test_softmin_rescale_branch_and_infinities(cuda):
     for flags in (0, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=flags).cpu().numpy()
         assert np.isfinite(out).all() and np.abs(out - ref).max() < 1.2e-6 + 2e-6 * np.abs(ref).max()
-    # lazy-max stress for the matrix-core path: exponents climbing by ~70 (base 2) every 64 columns, then a cliff
+    # lazy-max stress for the matrix-core path: exponents climbing by ~70 (base 2) every 64 columns (so every
+    # LDS tile overflows its speculative pass and is redone exactly), then a cliff, then one late spike
     h2 = (np.arange(M) // 64 * 48.0).astype(np.float32)
     h2[M // 2:] -= 3000.0
     h2[-3] = 5000.0
@@ -158,8 +161,16 @@ def test_kernel_conv_vs_oracle(cuda, kind, N, M, D):
     x, y, v = _clouds(31 + N, N, M, D)
     blur = 0.2
     ref = oracle_c.kconv(kind, x, y, v, blur)
-    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur).cpu().numpy()
+    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=hip.FLAG_NO_MFMA).cpu().numpy()
     assert relerr(out, ref) < 3e-6
+    # default path (gaussian, D <= 3: expanded exponent on the matrix cores): each kernel value carries a relative
+    # error ~2^-22 * |x - c|^2 / blur^2 with random sign
+    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur).cpu().numpy()
+    bound = oracle_c.kconv(kind, x, y, np.abs(v), blur) if kind == "gaussian" else None
+    tol = 3e-6 * np.abs(ref).max() + (2.4e-7 * D / blur**2 * np.abs(bound).max() if kind == "gaussian" else 0)
+    assert np.abs(out - ref).max() < tol
+    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=hip.FLAG_NO_SPLIT).cpu().numpy()
+    assert np.abs(out - ref).max() < tol
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -170,12 +181,13 @@ def test_kernel_conv_grads_vs_oracle(cuda, kind, D):
     y[:7] = x[:7]    # coincident points: |x-y| = 0 must give a zero direction, not NaN
     blur = 0.15
     g = np.random.default_rng(4).standard_normal(N).astype(np.float32)
-    xt, yt, vt = (_t(a, cuda).requires_grad_(True) for a in (x, y, v))
-    out = hip.kernel_conv(kind, xt, yt, vt, blur)
-    gx, gy, gv = torch.autograd.grad(out, [xt, yt, vt], grad_outputs=_t(g, cuda))
-    assert relerr(gx.cpu().numpy(), oracle_c.kconv_grad_x(kind, x, y, v, g, blur)) < 5e-6
-    assert relerr(gy.cpu().numpy(), oracle_c.kconv_grad_x(kind, y, x, g, v, blur)) < 5e-6
-    assert relerr(gv.cpu().numpy(), oracle_c.kconv(kind, y, x, g, blur)) < 5e-6
+    for flags, tol in ((hip.FLAG_NO_MFMA, 5e-6), (0, 5e-6 if kind != "gaussian" or D > 3 else 1e-4)):
+        xt, yt, vt = (_t(a, cuda).requires_grad_(True) for a in (x, y, v))
+        out = hip.kernel_conv(kind, xt, yt, vt, blur, flags=flags)
+        gx, gy, gv = torch.autograd.grad(out, [xt, yt, vt], grad_outputs=_t(g, cuda))
+        assert relerr(gx.cpu().numpy(), oracle_c.kconv_grad_x(kind, x, y, v, g, blur)) < tol
+        assert relerr(gy.cpu().numpy(), oracle_c.kconv_grad_x(kind, y, x, g, v, blur)) < tol
+        assert relerr(gv.cpu().numpy(), oracle_c.kconv(kind, y, x, g, blur)) < tol
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -185,12 +197,13 @@ def test_kernel_conv_block_sparse(cuda, kind):
     x, y, v = _clouds(29, N, M, D)
     rg, tup, tup_t, keep, ri = _random_ranges(rng, N, M, 8, 7, 0.5, cuda)
     blur = 0.3
-    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg).cpu().numpy()
-    assert relerr(out, oracle_c.kconv(kind, x, y, v, blur, ranges=tup)) < 3e-6
-    # transposed pattern (K^T @ g)
     g = rng.standard_normal(N).astype(np.float32)
-    out_t = hip.kernel_conv(kind, _t(y, cuda), _t(x, cuda), _t(g, cuda), blur, ranges=rg.t()).cpu().numpy()
-    assert relerr(out_t, oracle_c.kconv(kind, y, x, g, blur, ranges=tup_t)) < 3e-6
+    for flags, tol in ((hip.FLAG_NO_MFMA, 3e-6), (0, 3e-6 if kind != "gaussian" else 1e-4)):
+        out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg, flags=flags).cpu().numpy()
+        assert relerr(out, oracle_c.kconv(kind, x, y, v, blur, ranges=tup)) < tol
+        # transposed pattern (K^T @ g)
+        out_t = hip.kernel_conv(kind, _t(y, cuda), _t(x, cuda), _t(g, cuda), blur, ranges=rg.t(), flags=flags).cpu().numpy()
+        assert relerr(out_t, oracle_c.kconv(kind, y, x, g, blur, ranges=tup_t)) < tol
 
 
 @pytest.mark.parametrize("D", [4, 7, 16, 33])

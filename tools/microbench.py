@@ -46,11 +46,17 @@ def main():
         if "bwd" in what:
             out = hip.softmin_fwd_raw(xb, yb, hb, eps, 2)
             g = torch.ones_like(out)
-            res["softmin bwd p2"] = timeit(lambda: hip.softmin_bwd_x_raw(xb, yb, hb, out, g, eps, 2))
+            res["softmin bwd p2 (mfma)"] = timeit(lambda: hip.softmin_bwd_x_raw(xb, yb, hb, out, g, eps, 2))
+            res["softmin bwd p2 valu"] = timeit(lambda: hip.softmin_bwd_x_raw(xb, yb, hb, out, g, eps, 2, flags=2))
         v = torch.full((1, N), 1.0 / N, device=dev)
         for nm, kind in (("gauss", 0), ("lap", 1), ("energy", 2)):
             if nm in what:
                 res["conv " + nm] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05))
+                if nm == "gauss":
+                    res["conv gauss valu"] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05, flags=2))
+                    gg = torch.ones(1, N, device=dev)
+                    res["conv gauss bwd (mfma)"] = timeit(lambda: hip.kernel_conv_bwd_x_raw(kind, xb, yb, v, gg, 0.05))
+                    res["conv gauss bwd valu"] = timeit(lambda: hip.kernel_conv_bwd_x_raw(kind, xb, yb, v, gg, 0.05, flags=2))
         for k, (tmin, tmed) in res.items():
             print(f"N=M={N:>8d} {k:26s} min {tmin*1e3:10.3f} ms  med {tmed*1e3:10.3f} ms  {pairs/tmin:.3e} pairs/s")
 
