@@ -10,6 +10,7 @@
 #include "glhip_softmin_ops.h"
 #include "glhip_softmin_mfma.h"
 #include "glhip_wsum_mfma.h"
+#include "glhip_softmin_xdl.h"
 
 using namespace glhip;
 
@@ -78,7 +79,7 @@ void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_range
 // 2 row tiles per wavefront (128 rows per workgroup): 84-126 VGPRs -> 4-5 waves/SIMD; measured equal to 4 tiles at
 // N=M=1e6 and 11-16 % faster on mid-size, batched and block-sparse problems.
 constexpr int kFwdRT = 2;
-template <int D, typename T, int RT>
+template <int D, typename T, int RT, bool XDL = false>
 void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                          const Scratch& sc, hipStream_t st) {
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
@@ -91,12 +92,14 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     } else {
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
@@ -138,10 +141,11 @@ void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int 
 
 template <int D, bool BWD, typename T>
 void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
-                      bool direct, bool mfma, const Scratch& sc, hipStream_t st) {
+                      bool direct, bool mfma, bool xdl, const Scratch& sc, hipStream_t st) {
     if (p == 1) launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (direct) launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (!BWD && mfma) launch_softmin_mfma<D, T, kFwdRT>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma && xdl) launch_softmin_mfma<D, T, kFwdRT, true>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma) launch_softmin_mfma<D, T, kFwdRT, false>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (BWD && mfma) launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, st);
     else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
@@ -168,9 +172,10 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.out_scale = out_scale;
         prm.clamp2 = 1e-8f * prm.t * prm.t;
         const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
-        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
-        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
-        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, sc, st);
+        const bool xdl = (flags & GLHIP_FLAG_F32_MFMA) == 0;
+        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
+        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
+        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
     } else {
         if (BWD && D > kGenericMaxGradD)
             return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",

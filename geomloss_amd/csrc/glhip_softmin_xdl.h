@@ -1,57 +1,69 @@
-// glhip_softmin_mfma.h — soft-min forward (p = 2, D <= 3) with the exponents formed on the matrix cores.
+// glhip_softmin_xdl.h — soft-min forward (p = 2, D <= 3) with the exponents formed on the bf16 (XDL)
+// matrix pipe at fp32 accuracy ("bf16 x 3" splitting).
 //
-// The exponent of a pair in the expanded form is a length-4 dot product
-//     u_ij - r_i = [a_i0, a_i1, a_i2, 1] . [yt_j0, yt_j1, yt_j2, H_j]
-// i.e. a K = 4 fp32 GEMM tile, exactly what v_mfma_f32_16x16x4_f32 computes (fp32 in, fp32 accumulate,
-// bitwise an fmaf chain).  On CDNA4 the MFMA pipe runs beside the VALU pipe, so moving the 3 FMAs and the
-// "subtract the running max" (it becomes the C operand of the MFMA) off the VALU leaves it with only
-// exp2 / add / max per pair: 6.6 -> ~2.6 VALU instructions per pair.
-//
-// Layout (one wavefront = RT row tiles of 16 rows; 4 wavefronts per workgroup = 64*RT rows):
-//   A operand, per row tile: lane l holds A[i = l%16][k = l/16] = (a_i0 | a_i1 | a_i2 | 1)[k].
-//   B operand: lane l holds B[k = l/16][j = l%16].  The LDS tile stores, per super-group of 64 columns,
-//     one float4 per lane whose component g is the operand of column group g (16 columns); one
-//     conflict-free ds_read_b128 feeds 4 MFMAs per row tile.
-//   D: lane l, register r  <->  row 4*(l/16) + r, column l%16 of the group.  So each lane keeps the running
-//     (max, sum) of 4 rows over its own 1/16th of the columns; nothing crosses lanes until the final
-//     16-lane butterfly merge.
-// The running max is lazy.  The first 64 columns initialise m_i exactly (max over the 64 columns, shared by
-// the 16 lanes of the row).  After that a whole LDS tile (1024 columns) is accumulated speculatively with
-// C = -m and NO per-pair max / compare at all; only at the end of the tile the tile sums are checked: if
-// one passed kSumThr = 2^100 (a term ~2^80 above m arrived, or overflowed to +inf / NaN) the tile is redone
-// from the untouched old sums with exact per-group maxima (C = 0).  m <= true max always, nothing can
-// overflow unnoticed, and the hot loop is branch-free so the compiler can pipeline across column groups.
+// v_mfma_f32_16x16x4_f32 costs 34 cycles per 256 exponents — as much as the exp2 that follows.  The bf16
+// instruction v_mfma_f32_16x16x32_bf16 costs ~17 for the same 256 outputs and has K = 32 slots.  Every fp32
+// number is the exact sum of three bf16 numbers (8 + 8 + 8 significand bits, obtained by truncation), so
+//     a * y = (a1 + a2 + a3)(y1 + y2 + y3) = a1y1 + a1y2 + a2y1 + a1y3 + a3y1 + a2y2 + a2y3 + a3y2   (+ a3y3 ~ 2^-32)
+// — 8 exact bf16 products per coordinate, accumulated in fp32 by the MFMA.  K layout (4 blocks of 8 slots):
+//   block d < D : A = [a1,a1,a2,a1,a3,a2,a2,a3] of a_id,  B = [y1,y2,y1,y3,y1,y2,y3,y2] of yt_jd
+//   block 3     : A = [1,1,1,0,0,0,0,0],                  B = [H1,H2,H3,0,0,0,0,0]      (H_j split the same way)
+// and C = -running max as in the fp32 kernel.  Lane l holds K-block l/16 of row / column l%16, so one
+// 16-byte LDS record per (column, K-block) is the B operand as is.  D layout, lazy-max logic, column splits
+// and the merge are those of glhip_softmin_mfma.h.
 #pragma once
 
-#include "glhip_mapreduce.h"
-#include "glhip_softmin_ops.h"
+#include "glhip_softmin_mfma.h"
 
 namespace glhip {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kTileX = 512;                 // columns per LDS tile: 32 groups x 64 lanes x 16 B = 32 KiB
 
-constexpr int kMfmaRT = 4;                            // 16-row tiles per wavefront (weighted-sum kernels)
-constexpr int kMfmaRowsPerWave = kMfmaRT * 16;        // 64
-constexpr int kMfmaRowsPerBlock = 4 * kMfmaRowsPerWave;   // 256
-constexpr float kSumThr = 1.2676506e30f;            // 2^100: refresh the lazy max when a row sum passes it
-constexpr float kMinusHuge = -3.0e38f;
+union Pack16 { uint4 u; bf16x8 v; };
 
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 exp2v(f32x4 v) {
-    return f32x4{fast_exp2(v.x), fast_exp2(v.y), fast_exp2(v.z), fast_exp2(v.w)};
-}
-__device__ __forceinline__ f32x4 maxv(f32x4 a, f32x4 b) {
-    return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+// three bf16 numbers (as the high halves of fp32 bit patterns) whose sum is v, by truncation
+__device__ __forceinline__ void split3(float v, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t b1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float f1 = __uint_as_float(b1);
+    float r = v - f1;                                  // exact
+    if ((b1 & 0x7F800000u) == 0x7F800000u) r = 0.f;    // inf / nan stay in the first piece only
+    const uint32_t b2 = __float_as_uint(r) & 0xFFFF0000u;
+    const float r2 = r - __uint_as_float(b2);          // exact
+    p1 = b1 >> 16;
+    p2 = b2 >> 16;
+    p3 = __float_as_uint(r2) >> 16;
 }
 
-template <int D, typename T, bool SPARSE, int RT = kMfmaRT>
+__device__ __forceinline__ uint4 pack_a(float a) {     // [a1,a1,a2,a1,a3,a2,a2,a3]
+    uint32_t p1, p2, p3;
+    split3(a, p1, p2, p3);
+    return uint4{p1 | (p1 << 16), p2 | (p1 << 16), p3 | (p2 << 16), p2 | (p3 << 16)};
+}
+__device__ __forceinline__ uint4 pack_y(float y) {     // [y1,y2,y1,y3,y1,y2,y3,y2]
+    uint32_t p1, p2, p3;
+    split3(y, p1, p2, p3);
+    return uint4{p1 | (p2 << 16), p1 | (p3 << 16), p1 | (p2 << 16), p3 | (p2 << 16)};
+}
+__device__ __forceinline__ uint4 pack_h(float h) {     // [H1,H2,H3,0,0,0,0,0]
+    uint32_t p1, p2, p3;
+    split3(h, p1, p2, p3);
+    return uint4{p1 | (p2 << 16), p3, 0u, 0u};
+}
+
+__device__ __forceinline__ f32x4 mfma_x(const uint4& a, const uint4& b, f32x4 c) {
+    Pack16 pa, pb;
+    pa.u = a;
+    pb.u = b;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa.v, pb.v, c, 0, 0, 0);
+}
+
+template <int D, typename T, bool SPARSE, int RT>
 __global__ void __launch_bounds__(kBlock)
-softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+softmin_fwd_xdl_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerWave = RT * 16;
     constexpr int kRowsPerBlock = 4 * kRowsPerWave;
-    __shared__ f32x4 tileB[kTile];   // [super-group][lane] -> 4 column groups
+    __shared__ uint4 tileX[(kTileX / 16) * 64];   // [column group][lane = kblock*16 + j]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,7 +71,7 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
     const int b = blockIdx.y;
     const int split = blockIdx.z;
     const int ns = sp.n_splits;
-    const int lk = lane >> 4;   // k index of this lane's A/B element; also the 4-row group of its D rows
+    const int lk = lane >> 4;
     const int lj = lane & 15;
 
     int row_begin, row_end, q_begin, q_end;
@@ -69,15 +81,15 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
         float centre[D];
         load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
-        // A operands of this wavefront's row tiles
         const int wave_row0 = row0 + wave * kRowsPerWave;
-        float A[RT];
+        uint4 A[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int i = min(wave_row0 + rt * 16 + lj, row_end - 1);
-            float v = (lk == 3) ? 1.0f : 0.0f;
-            if (lk < D) v = (to_f32<T>(prm.x[((long)b * N + i) * D + lk]) - centre[lk < D ? lk : 0]) * prm.s2;
-            A[rt] = v;
+            uint4 a = uint4{0u, 0u, 0u, 0u};
+            if (lk < D) a = pack_a((to_f32<T>(prm.x[((long)b * N + i) * D + (lk < D ? lk : 0)]) - centre[lk < D ? lk : 0]) * prm.s2);
+            else if (lk == 3) a = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // 1, 1, 1
+            A[rt] = a;
         }
         f32x4 negm[RT], ssum[RT];
 #pragma unroll
@@ -92,11 +104,10 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
         for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
             int js, je;
             column_interval<SPARSE>(rg, M, q, split, ns, js, je);
-            for (int j0 = js; j0 < je; j0 += kTile) {
-                const int n = min(kTile, je - j0);
+            for (int j0 = js; j0 < je; j0 += kTileX) {
+                const int n = min(kTileX, je - j0);
                 const int npad = (n + 63) & ~63;
                 __syncthreads();
-                // stage: column t -> component g of lanes (k*16 + j) of super-group G
                 for (int t = tid; t < npad; t += kBlock) {
                     float rec[4] = {0.f, 0.f, 0.f, kNegBig};
                     if (t < n) {
@@ -110,30 +121,31 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
                         }
                         rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, prm.h[(long)b * M + j0 + t] * kLog2e);
                     }
-                    const int G = t >> 6, g = (t >> 4) & 3, j = t & 15;
-                    float* base = reinterpret_cast<float*>(&tileB[G * 64]);
+                    uint4* base = &tileX[(t >> 4) * 64 + (t & 15)];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) base[(k * 16 + j) * 4 + g] = rec[k];
+                    for (int d = 0; d < 3; ++d) base[d * 16] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
+                    base[48] = pack_h(rec[3]);
                 }
                 __syncthreads();
                 if (!wave_active) continue;
 
-                const int nG = npad / 64;
+                const int nG = npad / 64;   // super-groups of 4 column groups
                 int G0 = 0;
                 if (first_group) {
-                    // exact initialisation on the first 64 columns; the max is shared by the 16 lanes of a row
-                    const f32x4 B4 = tileB[lane];
+                    uint4 Bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Bq[g] = tileX[g * 64 + lane];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const f32x4 u0 = mfma4(A[rt], B4.x, zero), u1 = mfma4(A[rt], B4.y, zero);
-                        const f32x4 u2 = mfma4(A[rt], B4.z, zero), u3 = mfma4(A[rt], B4.w, zero);
+                        const f32x4 u0 = mfma_x(A[rt], Bq[0], zero), u1 = mfma_x(A[rt], Bq[1], zero);
+                        const f32x4 u2 = mfma_x(A[rt], Bq[2], zero), u3 = mfma_x(A[rt], Bq[3], zero);
                         f32x4 um = maxv(maxv(u0, u1), maxv(u2, u3));
 #pragma unroll
                         for (int off = 1; off < 16; off <<= 1) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) um[r] = fmaxf(um[r], __shfl_xor(um[r], off, 64));
                         }
-                        um = maxv(um, f32x4{kMinusHuge, kMinusHuge, kMinusHuge, kMinusHuge});   // -inf columns only
+                        um = maxv(um, f32x4{kMinusHuge, kMinusHuge, kMinusHuge, kMinusHuge});
                         negm[rt] = -um;
                         ssum[rt] = (exp2v(u0 - um) + exp2v(u1 - um)) + (exp2v(u2 - um) + exp2v(u3 - um));
                     }
@@ -141,18 +153,19 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
                     G0 = 1;
                 }
 
-                // speculative, branch-free pass over the tile
                 f32x4 stmp[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) stmp[rt] = zero;
                 for (int G = G0; G < nG; ++G) {
-                    const f32x4 B4 = tileB[G * 64 + lane];
+                    uint4 Bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Bq[g] = tileX[(G * 4 + g) * 64 + lane];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const f32x4 d0 = mfma4(A[rt], B4.x, negm[rt]);
-                        const f32x4 d1 = mfma4(A[rt], B4.y, negm[rt]);
-                        const f32x4 d2 = mfma4(A[rt], B4.z, negm[rt]);
-                        const f32x4 d3 = mfma4(A[rt], B4.w, negm[rt]);
+                        const f32x4 d0 = mfma_x(A[rt], Bq[0], negm[rt]);
+                        const f32x4 d1 = mfma_x(A[rt], Bq[1], negm[rt]);
+                        const f32x4 d2 = mfma_x(A[rt], Bq[2], negm[rt]);
+                        const f32x4 d3 = mfma_x(A[rt], Bq[3], negm[rt]);
                         stmp[rt] += (exp2v(d0) + exp2v(d1)) + (exp2v(d2) + exp2v(d3));
                     }
                 }
@@ -161,13 +174,14 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
                 for (int rt = 0; rt < RT; ++rt)
                     smax = fmaxf(fmaxf(smax, stmp[rt].x), fmaxf(fmaxf(stmp[rt].y, stmp[rt].z), stmp[rt].w));
                 if (__any(!(smax < kSumThr))) {
-                    // redo the tile from the old sums with exact per-group maxima
                     for (int G = G0; G < nG; ++G) {
-                        const f32x4 B4 = tileB[G * 64 + lane];
+                        uint4 Bq[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) Bq[g] = tileX[(G * 4 + g) * 64 + lane];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) {
-                            const f32x4 u0 = mfma4(A[rt], B4.x, zero), u1 = mfma4(A[rt], B4.y, zero);
-                            const f32x4 u2 = mfma4(A[rt], B4.z, zero), u3 = mfma4(A[rt], B4.w, zero);
+                            const f32x4 u0 = mfma_x(A[rt], Bq[0], zero), u1 = mfma_x(A[rt], Bq[1], zero);
+                            const f32x4 u2 = mfma_x(A[rt], Bq[2], zero), u3 = mfma_x(A[rt], Bq[3], zero);
                             const f32x4 mold = -negm[rt];
                             const f32x4 mnew = maxv(mold, maxv(maxv(u0, u1), maxv(u2, u3)));
                             negm[rt] = -mnew;
@@ -183,7 +197,6 @@ softmin_fwd_mfma_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo
         }
 
         if (wave_active) {
-            // merge the 16 column-lanes of every row, then lane (l%16 == r) finishes row 4*(l/16) + r
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 m = -negm[rt], s = ssum[rt];

@@ -6,8 +6,9 @@
 //   WS_GAUSS_FWD   : gaussian kernel product.  C_i = r_i = -s/2 |xt_i|^2, H_j = -s/2 |yt_j|^2, s = log2(e)/blur^2,
 //                    weights k_ij <= 1;  q_j = v_j.
 //   WS_GAUSS_BWD   : its gradient in x.  q_j = (v_j yt_j, v_j);  grad = -(g_i/blur^2) (xt_i S0 - S1).
-// Exponents are <= 0 by construction, so there is no running max.  Same wave / LDS layout as the forward
-// soft-min (glhip_softmin_mfma.h): lane l holds D rows 4*(l/16)+r and column l%16 of each 16-column group.
+// Exponents are <= 0 by construction, so there is no running max.  Same wave / LDS layout and the same
+// bf16 x 3 exponent MFMA as the forward soft-min (glhip_softmin_xdl.h): lane l holds D rows 4*(l/16)+r and
+// column l%16 of each 16-column group.
 // q is staged as tileQ[c][G][j] = float4 over the 4 column groups of super-group G: the 4 lanes that share a
 // column read the same 16 bytes (broadcast), the 16 columns are contiguous (conflict-free).
 //
@@ -17,7 +18,7 @@
 // (GLHIP_FLAG_NO_MFMA) and are what laplacian / energy / p = 1 always use.
 #pragma once
 
-#include "glhip_softmin_mfma.h"
+#include "glhip_softmin_xdl.h"
 
 namespace glhip {
 
@@ -38,6 +39,17 @@ struct WsumParams {
     float tscale;       // WS_GAUSS_BWD: coordinate pre-scale of the VALU operator (partials are stored in its units)
 };
 
+// acc[r] += w[r] * q.  NOTE (measured on MI355X, ROCm 7.2): when this was emitted as v_pk_fma_f32 and the
+// next instruction was an XDL MFMA whose vdst reused the pk op's source registers (WAR), the low result of
+// the pk op was sporadically lost in lanes 48-63 (one row of the gaussian gradient off by exactly one column
+// group's contribution, in ~9 of 10 processes).  hipcc pads no hazard there.  The library is therefore built
+// with packed fp32 math disabled (-target-feature -packed-fp32-ops, see csrc/Makefile); cost: ~5 % on the
+// forward kernel, nothing elsewhere.
+__device__ __forceinline__ void fma4(f32x4& acc, const f32x4& w, float q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(w[r], q, acc[r]);
+}
+
 template <int MODE, int D> struct WsumShape {
     static constexpr int kNQ = (MODE == WS_SOFTMIN_BWD) ? D : (MODE == WS_GAUSS_FWD ? 1 : D + 1);   // LDS q vectors
     static constexpr int kNA = (MODE == WS_GAUSS_FWD) ? 1 : D + 1;                                  // accumulators
@@ -50,8 +62,8 @@ __global__ void __launch_bounds__(kBlock)
 wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int NQ = WsumShape<MODE, D>::kNQ;
     constexpr int NA = WsumShape<MODE, D>::kNA;
-    __shared__ f32x4 tileB[kTile];
-    __shared__ f32x4 tileQ[NQ * (kTile / 64) * 16];
+    __shared__ uint4 tileX[(kTileX / 16) * 64];          // bf16 x 3 B operands, as in softmin_fwd_xdl_kernel
+    __shared__ f32x4 tileQ[NQ * (kTileX / 64) * 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,15 +83,16 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         const int wave_row0 = row0 + wave * kMfmaRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
 
-        float A[kMfmaRT];
+        uint4 A[kMfmaRT];
         f32x4 Cop[kMfmaRT];                // per-row constant added to every exponent
         f32x4 acc[kMfmaRT][NA];
 #pragma unroll
         for (int rt = 0; rt < kMfmaRT; ++rt) {
             const int i = min(wave_row0 + rt * 16 + lj, row_end - 1);
-            float v = (lk == 3) ? 1.0f : 0.0f;
-            if (lk < D) v = (to_f32<T>(prm.x[((long)b * N + i) * D + lk]) - centre[lk < D ? lk : 0]) * prm.s2;
-            A[rt] = v;
+            uint4 a = uint4{0u, 0u, 0u, 0u};
+            if (lk < D) a = pack_a((to_f32<T>(prm.x[((long)b * N + i) * D + (lk < D ? lk : 0)]) - centre[lk < D ? lk : 0]) * prm.s2);
+            else if (lk == 3) a = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};
+            A[rt] = a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ir = min(wave_row0 + rt * 16 + lk * 4 + r, row_end - 1);
@@ -102,8 +115,8 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
             int js, je;
             column_interval<SPARSE>(rg, M, q, split, ns, js, je);
-            for (int j0 = js; j0 < je; j0 += kTile) {
-                const int n = min(kTile, je - j0);
+            for (int j0 = js; j0 < je; j0 += kTileX) {
+                const int n = min(kTileX, je - j0);
                 const int npad = (n + 63) & ~63;
                 __syncthreads();
                 for (int t = tid; t < npad; t += kBlock) {
@@ -136,33 +149,36 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         }
                     }
                     const int G = t >> 6, g = (t >> 4) & 3, j = t & 15;
-                    float* base = reinterpret_cast<float*>(&tileB[G * 64]);
+                    uint4* base = &tileX[(t >> 4) * 64 + j];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) base[(k * 16 + j) * 4 + g] = rec[k];
+                    for (int d = 0; d < 3; ++d) base[d * 16] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
+                    base[48] = pack_h(rec[3]);
 #pragma unroll
                     for (int c = 0; c < NQ; ++c)
-                        reinterpret_cast<float*>(&tileQ[(c * (kTile / 64) + G) * 16 + j])[g] = qv[c];
+                        reinterpret_cast<float*>(&tileQ[(c * (kTileX / 64) + G) * 16 + j])[g] = qv[c];
                 }
                 __syncthreads();
                 if (!wave_active) continue;
 
                 for (int G = 0; G < npad / 64; ++G) {
-                    const f32x4 B4 = tileB[G * 64 + lane];
+                    uint4 Bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Bq[g] = tileX[(G * 4 + g) * 64 + lane];
                     f32x4 Q[NQ];
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c) Q[c] = tileQ[(c * (kTile / 64) + G) * 16 + lj];
+                    for (int c = 0; c < NQ; ++c) Q[c] = tileQ[(c * (kTileX / 64) + G) * 16 + lj];
 #pragma unroll
                     for (int rt = 0; rt < kMfmaRT; ++rt) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const f32x4 w = exp2v(mfma4(A[rt], B4[g], Cop[rt]));
+                            const f32x4 w = exp2v(mfma_x(A[rt], Bq[g], Cop[rt]));
                             if (MODE == WS_SOFTMIN_BWD) {
 #pragma unroll
-                                for (int d = 0; d < D; ++d) acc[rt][d] += w * Q[d][g];
+                                for (int d = 0; d < D; ++d) fma4(acc[rt][d], w, Q[d][g]);
                                 acc[rt][D] += w;
                             } else {
 #pragma unroll
-                                for (int c = 0; c < NQ; ++c) acc[rt][c] += w * Q[c][g];
+                                for (int c = 0; c < NQ; ++c) fma4(acc[rt][c], w, Q[c][g]);
                             }
                         }
                     }
@@ -182,43 +198,48 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         for (int r = 0; r < 4; ++r) acc[rt][c][r] += __shfl_xor(acc[rt][c][r], off, 64);
                     }
                 }
-                float a_[NA];
+                // the first lane of each 16-lane group writes the group's 4 rows (no per-lane select chains)
+                if (lj == 0) {
 #pragma unroll
-                for (int c = 0; c < NA; ++c)
-                    a_[c] = (lj == 0) ? acc[rt][c].x : (lj == 1) ? acc[rt][c].y : (lj == 2) ? acc[rt][c].z : acc[rt][c].w;
-                const int i = wave_row0 + rt * 16 + lk * 4 + lj;
-                if (lj < 4 && i < row_end) {
-                    float xt[D];
-                    {
-                        float xi[D];
-                        load_point<D, T>(prm.x, (long)b * N + i, xi);
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = wave_row0 + rt * 16 + lk * 4 + r;
+                        if (i < row_end) {
+                            float a_[NA];
 #pragma unroll
-                        for (int d = 0; d < D; ++d) xt[d] = xi[d] - centre[d];
-                    }
-                    float* part = sp.workspace + split * sp.split_stride + ((long)b * N + i) * WsumShape<MODE, D>::kPart;
-                    if (MODE == WS_SOFTMIN_BWD) {
-                        if (ns == 1) {
-                            const float gi = prm.g[(long)b * N + i];
-                            const float inv = (a_[D] > 0.f) ? 1.0f / a_[D] : 0.f;
+                            for (int c = 0; c < NA; ++c) a_[c] = acc[rt][c][r];
+                            float xt[D];
+                            {
+                                float xi[D];
+                                load_point<D, T>(prm.x, (long)b * N + i, xi);
 #pragma unroll
-                            for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] - a_[d] * inv);
-                        } else {
+                                for (int d = 0; d < D; ++d) xt[d] = xi[d] - centre[d];
+                            }
+                            float* part = sp.workspace + split * sp.split_stride + ((long)b * N + i) * WsumShape<MODE, D>::kPart;
+                            if (MODE == WS_SOFTMIN_BWD) {
+                                if (ns == 1) {
+                                    const float gi = prm.g[(long)b * N + i];
+                                    const float inv = (a_[D] > 0.f) ? 1.0f / a_[D] : 0.f;
 #pragma unroll
-                            for (int c = 0; c < NA; ++c) part[c] = a_[c];
-                        }
-                    } else if (MODE == WS_GAUSS_FWD) {
-                        if (ns == 1) prm.out[(long)b * N + i] = a_[0];
-                        else part[0] = a_[0];
-                    } else {
-                        // sum_j v k (x - y) = xt S0 - S1
-                        if (ns == 1) {
-                            const float gi = prm.g[(long)b * N + i] * prm.gscale;
+                                    for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] - a_[d] * inv);
+                                } else {
 #pragma unroll
-                            for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] * a_[D] - a_[d]);
-                        } else {
-                            // partials in the units of ConvOp<GAUSSIAN,...,BWD>::merge_row (scaled differences)
+                                    for (int c = 0; c < NA; ++c) part[c] = a_[c];
+                                }
+                            } else if (MODE == WS_GAUSS_FWD) {
+                                if (ns == 1) prm.out[(long)b * N + i] = a_[0];
+                                else part[0] = a_[0];
+                            } else {
+                                // sum_j v k (x - y) = xt S0 - S1
+                                if (ns == 1) {
+                                    const float gi = prm.g[(long)b * N + i] * prm.gscale;
 #pragma unroll
-                            for (int d = 0; d < D; ++d) part[d] = prm.tscale * (xt[d] * a_[D] - a_[d]);
+                                    for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] * a_[D] - a_[d]);
+                                } else {
+                                    // partials in the units of ConvOp<GAUSSIAN,...,BWD>::merge_row (scaled differences)
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) part[d] = prm.tscale * (xt[d] * a_[D] - a_[d]);
+                                }
+                            }
                         }
                     }
                 }

@@ -58,8 +58,9 @@ extern "C" {
 /* flags (bitmask) */
 #define GLHIP_FLAG_DIRECT 1   /* p=2 softmin: evaluate |x-y|^2 as sum (x_d-y_d)^2 (KeOps' SqDist)
                                  instead of the per-workgroup-centred expansion. Slower, tighter. */
-#define GLHIP_FLAG_NO_MFMA 2  /* p=2 softmin forward: form the exponents on the VALU instead of the matrix cores */
+#define GLHIP_FLAG_NO_MFMA 2  /* p=2 softmin / gaussian: form the exponents on the VALU instead of the matrix cores */
 #define GLHIP_FLAG_NO_SPLIT 4 /* never split the columns of a row over several workgroups (ignore the workspace) */
+#define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split */
 
 /* error codes */
 #define GLHIP_OK 0

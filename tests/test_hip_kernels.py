@@ -44,7 +44,7 @@ def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
     x, y, h = _clouds(N + M + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, p)
     # every code path of the forward kernel: matrix-core / VALU exponents, with / without column splits
-    for flags in (0, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
+    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, 8 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags  # diam^2 <= D on the unit cube
     out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
@@ -100,7 +100,7 @@ def test_softmin_rescale_branch_and_infinities(cuda):
     h[6] = -100000.0
     eps = 0.05**2
     ref = oracle_c.softmin(eps, x, y, h, 2)
-    for flags in (0, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT):
+    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=flags).cpu().numpy()
         assert np.isfinite(out).all() and np.abs(out - ref).max() < 1.2e-6 + 2e-6 * np.abs(ref).max()
     # lazy-max stress for the matrix-core path: exponents climbing by ~70 (base 2) every 64 columns (so every
@@ -109,7 +109,7 @@ def test_softmin_rescale_branch_and_infinities(cuda):
     h2[M // 2:] -= 3000.0
     h2[-3] = 5000.0
     ref2 = oracle_c.softmin(eps, x, y, h2, 2)
-    for flags in (0, hip.FLAG_NO_MFMA):
+    for flags in (0, 8, hip.FLAG_NO_MFMA):
         out2 = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h2, cuda), flags=flags).cpu().numpy()
         assert np.isfinite(out2).all() and relerr(out2, ref2) < 2e-6
 
@@ -139,7 +139,7 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     empty = slice(ri[0, 0], ri[0, 1])
     live = np.ones(N, bool)
     live[empty] = False
-    for flags in (0, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
+    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, ranges=rg, flags=flags).cpu().numpy()
         assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()   # LSE over the empty set
         assert np.abs(out[live] - ref[live]).max() < 1.2e-6 + 2e-6 * np.abs(ref[live]).max()

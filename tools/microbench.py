@@ -35,7 +35,8 @@ def main():
         what = args.what.split(",")
         res = {}
         if "softmin" in what:
-            res["softmin p2 (mfma+split)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
+            res["softmin p2 (xdl bf16x3)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
+            res["softmin p2 f32 mfma"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=8))
             res["softmin p2 mfma nosplit"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=4))
             res["softmin p2 valu split"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=2))
             res["softmin p2 valu nosplit"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=6))
