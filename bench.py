@@ -37,8 +37,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (one fp32 VALU op / lane / clk)
-VALU_OPS_PER_PAIR = 6.6          # instruction count of the inner loop (profiles/r01_isa_softmin_fwd.txt)
+# Issue-bound model of the default kernel (softmin_fwd_xdl_kernel), from the micro-benchmark in
+# profiles/r01_ubench_pipes.txt: per 64 pairs one v_exp_f32 (8.5 cycles), a quarter of a
+# v_mfma_f32_16x16x32_bf16 (17.5 / 4) and one v_add_f32 (2.5), which do not overlap on a SIMD.
+ISSUE_CYCLES_PER_64_PAIRS = 8.5 + 17.5 / 4 + 2.5
+ISSUE_CEILING_PAIRS_PER_S = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_64_PAIRS
 
 
 def log(*a):
@@ -214,13 +217,14 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "model": "dense-equivalent: 4 algorithmic bytes per pair (SURVEY §8d); the kernel is VALU-bound, "
+                "model": "dense-equivalent: 4 algorithmic bytes per pair (SURVEY §8d); the kernel is issue-bound (exp2 + MFMA), "
                          "frac > 1 means it beats what any kernel streaming the fp32 cost matrix could reach",
-                "kernel": "mapreduce_kernel<SoftminFwdOp<3,2,false,2,float>,false>",
+                "kernel": "softmin_fwd_xdl_kernel<3,float,false,2> (+ merge_kernel when the columns are split)",
                 "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
                 "compulsory_bytes_per_launch": compulsory, "compulsory_GBs": compulsory / (kernel_ms * 1e-3) / 1e9,
-                "valu_frac": kernel_pairs_s * VALU_OPS_PER_PAIR / VALU_LANE_OPS_PER_S,
-                "valu_model": f"{VALU_OPS_PER_PAIR} VALU instructions per pair over 256 CU x 128 lanes x 2.4 GHz",
+                "issue_model_frac": kernel_pairs_s / ISSUE_CEILING_PAIRS_PER_S,
+                "issue_model": f"{ISSUE_CYCLES_PER_64_PAIRS:.2f} SIMD cycles per 64 pairs (v_exp_f32 8.5 + bf16 MFMA 17.5/4 + "
+                               f"v_add_f32 2.5, measured, non-overlapping) -> {ISSUE_CEILING_PAIRS_PER_S:.3g} pairs/s at 2.4 GHz",
             },
         }
         if world == 1 and not args.no_extras:
