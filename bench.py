@@ -202,8 +202,8 @@ def main():
                 traffic = None
         compulsory = 4.0 * (n * 3 + n * 4 + n)
         res = {
-            "metric": "softmin pairs/s (dense soft-min reduction, N=M=1e6 3D fp32)" if n == 1_000_000
-                      else f"softmin pairs/s (N=M={n} 3D fp32)",
+            "metric": "softmin pairs/s, N=M=1e6 3D fp32 (Sinkhorn wall-clock: `sinkhorn_wallclock`; % HBM roofline: `roofline`)"
+                      if n == 1_000_000 else f"softmin pairs/s (N=M={n} 3D fp32)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -10,6 +10,7 @@ a tensor is not on a GPU, the call raises.
 
 import ctypes
 import os
+import warnings
 
 import torch
 
@@ -41,6 +42,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_warned = {"f64": False}
 
 
 def load_library(path=None):
@@ -89,6 +91,10 @@ def _points(t, name):
             "Use backend='tensorized' for CPU tensors."
         )
     if t.dtype not in (torch.float32, torch.bfloat16):
+        if t.dtype == torch.float64 and not _warned["f64"]:
+            _warned["f64"] = True
+            warnings.warn("geomloss_amd: the HIP kernels compute in fp32; float64 inputs are cast down "
+                          "(use backend='tensorized' for double precision).")
         t = t.float()
     return t.contiguous()
 
