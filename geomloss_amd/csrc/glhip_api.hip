@@ -150,10 +150,16 @@ void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_range
     else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
+struct StepArgs {   // fused Sinkhorn half-step; all-default = plain soft-min
+    const float* pot = nullptr;
+    const float* prev = nullptr;
+    float alpha = 1.f, beta = 0.f;
+};
+
 template <bool BWD, typename T>
 int softmin_typed(const void* x, const void* y, const float* h, float* out, const float* fwd, const float* g,
                   float* gx, int B, int N, int M, int D, float eps, int p, const Ranges& rg, int n_ranges,
-                  const Scratch& sc, int flags, hipStream_t st) {
+                  const Scratch& sc, int flags, hipStream_t st, const StepArgs& step = StepArgs()) {
     const float s2 = kLog2e / eps;
     const float out_scale = -eps * kLn2;
     if (D <= 3) {
@@ -171,12 +177,19 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.inv_t = 1.0f / prm.t;
         prm.out_scale = out_scale;
         prm.clamp2 = 1e-8f * prm.t * prm.t;
+        prm.pot = step.pot;
+        prm.prev = step.prev;
+        prm.pot_scale = 1.0f / eps;
+        prm.alpha = step.alpha;
+        prm.beta = step.beta;
         const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
         const bool xdl = (flags & GLHIP_FLAG_F32_MFMA) == 0;
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
     } else {
+        if (step.pot || step.prev || step.alpha != 1.f)
+            return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: D=%d > 3 has no fused kernel (use glhip_softmin_fwd)", D);
         if (BWD && D > kGenericMaxGradD)
             return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
                         D, kGenericMaxGradD);
@@ -336,6 +349,31 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
              ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
              : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
     return rc ? rc : check_launch("glhip_softmin_fwd");
+}
+
+int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const float* pot, const float* prev,
+                        float* out, int B, int N, int M, int D, float eps, float damping, int p, int in_dtype,
+                        const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                        void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_sinkhorn_step", x, y, logw, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (!out) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: NULL out");
+    if (out == prev) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: out must not alias prev (updates are simultaneous)");
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: eps must be > 0");
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: p must be 1 or 2 (got %d)", p);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    StepArgs step;
+    step.pot = pot;
+    step.prev = prev;
+    step.alpha = prev ? 0.5f * damping : damping;
+    step.beta = prev ? 0.5f : 0.f;
+    rc = (in_dtype == GLHIP_F32)
+             ? softmin_typed<false, float>(x, y, logw, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step)
+             : softmin_typed<false, bf16_t>(x, y, logw, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step);
+    return rc ? rc : check_launch("glhip_sinkhorn_step");
 }
 
 int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const float* out, const float* grad_out,

@@ -36,7 +36,27 @@ struct SoftminParams {
     float inv_t;       // 1 / t
     float out_scale;   // -eps * ln(2)
     float clamp2;      // p = 1: floor on the (scaled) squared distance, 1e-8 * t^2 (utils.py:61)
+    // fused Sinkhorn half-step (glhip_sinkhorn_step): h_j := h_j + pot_scale * pot_j ;  out_i := alpha * f_i + beta * prev_i
+    const float* pot;  // (B,M) or NULL
+    const float* prev; // (B,N) or NULL
+    float pot_scale;   // 1 / eps
+    float alpha, beta; // 1, 0 for the plain soft-min
 };
+
+// dual vector entry j as the kernels see it (natural-log units)
+template <typename T>
+__device__ __forceinline__ float dual_entry(const SoftminParams<T>& p, long idx) {
+    float hj = p.h[idx];
+    if (p.pot) hj = __builtin_fmaf(p.pot[idx], p.pot_scale, hj);
+    return hj;
+}
+// final value written for row idx from its base-2 log-sum-exp
+template <typename T>
+__device__ __forceinline__ float finish_value(const SoftminParams<T>& p, long idx, float lse2) {
+    float f = p.alpha * (p.out_scale * lse2);
+    if (p.prev) f = __builtin_fmaf(p.beta, p.prev[idx], f);
+    return f;
+}
 
 // ---- shared pieces ---------------------------------------------------------------------------
 
@@ -140,7 +160,7 @@ struct SoftminFwdOp {
             n2 = __builtin_fmaf(yt, yt, n2);
             rec.c[d] = DIRECT ? yt * p.t : yt;
         }
-        const float hj = p.h[(long)b * M + j] * kLog2e;
+        const float hj = dual_entry(p, (long)b * M + j) * kLog2e;
         rec_tail<D_>(rec) = DIRECT ? hj : __builtin_fmaf(-0.5f * p.s2, n2, hj);
         if (D_ == 2) rec.c[3] = 0.f;
         return rec;
@@ -175,7 +195,7 @@ struct SoftminFwdOp {
             const int i = row0 + r * kBlock + tid;
             if (i < row_end) {
                 const float lse2 = st.r[r] + st.m[r] + fast_log2(st.s[r]);
-                p.out[(long)b * N + i] = p.out_scale * lse2;
+                p.out[(long)b * N + i] = finish_value(p, (long)b * N + i, lse2);
             }
         }
     }
@@ -195,7 +215,7 @@ struct SoftminFwdOp {
             s = s * fast_exp2(m - mn) + sk * fast_exp2(mk - mn);
             m = mn;
         }
-        p.out[(long)b * N + i] = p.out_scale * (m + fast_log2(s));
+        p.out[(long)b * N + i] = finish_value(p, (long)b * N + i, m + fast_log2(s));
     }
 };
 

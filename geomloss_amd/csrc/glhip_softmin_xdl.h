@@ -119,7 +119,7 @@ softmin_fwd_xdl_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
                             rec[d] = yj[d] - centre[d];
                             n2 = __builtin_fmaf(rec[d], rec[d], n2);
                         }
-                        rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, prm.h[(long)b * M + j0 + t] * kLog2e);
+                        rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, (long)b * M + j0 + t) * kLog2e);
                     }
                     uint4* base = &tileX[(t >> 4) * 64 + (t & 15)];
 #pragma unroll
@@ -229,7 +229,7 @@ softmin_fwd_xdl_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
                             }
                             const float mtot = __builtin_fmaf(-0.5f * prm.s2, n2, m[r]);   // r_i + m
                             if (ns == 1) {
-                                prm.out[(long)b * N + i] = prm.out_scale * (mtot + fast_log2(s[r]));
+                                prm.out[(long)b * N + i] = finish_value(prm, (long)b * N + i, mtot + fast_log2(s[r]));
                             } else {
                                 float* dst = sp.workspace + split * sp.split_stride + ((long)b * N + i) * 2;
                                 dst[0] = mtot;

@@ -32,6 +32,8 @@ SIGNATURES = {
     "glhip_workspace_bytes": (_c_size, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "glhip_softmin_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int]
                           + _RANGES + _TAIL),
+    "glhip_sinkhorn_step": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                     _c_int, _c_int] + _RANGES + _TAIL),
     "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
                                      _c_int] + _RANGES + _TAIL),
     "glhip_kernel_conv_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int]
@@ -175,6 +177,22 @@ def softmin_fwd_raw(x, y, h, eps, p=2, ranges=None, flags=0):
     return out
 
 
+def sinkhorn_step_raw(x, y, logw, pot, prev, eps, damping, p=2, ranges=None, flags=0):
+    """Fused half-step: (prev + damping * softmin(eps, C(x,y), logw + pot/eps)) / 2, or damping * softmin(...) if prev is None."""
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
+        rc = lib.glhip_sinkhorn_step(x.data_ptr(), y.data_ptr(), logw.data_ptr(),
+                                     None if pot is None else pot.data_ptr(), None if prev is None else prev.data_ptr(),
+                                     out.data_ptr(), B, N, M, D, float(eps), float(damping), int(p), _dtype_code(x),
+                                     *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
+    _check(rc, lib)
+    return out
+
+
 def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
@@ -265,6 +283,21 @@ ENV_FLAGS = int(os.environ.get("GEOMLOSS_HIP_FLAGS", "0"))
 def softmin(eps, x, y, h, p=2, ranges=None, flags=0):
     """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32."""
     return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS)
+
+
+def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0):
+    """One fused, non-differentiable half-step of the Sinkhorn loop on the GPU (D <= 3).
+
+    x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); logw, pot: (M,)|(B,M) (pot may be None); prev: (N,)|(B,N) or None.
+    Returns fp32 (N,)|(B,N).  Used by the drivers inside the no-grad part of ``sinkhorn_loop``."""
+    xb, yb, lw, batched = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(logw))
+    if yb.dtype != xb.dtype:
+        yb = yb.to(xb.dtype)
+    B = xb.shape[0]
+    pt = None if pot is None else _f32(pot).reshape(B, -1)
+    pv = None if prev is None else _f32(prev).reshape(B, -1)
+    out = sinkhorn_step_raw(xb, yb, lw, pt, pv, eps, damping, p, ranges, int(flags) | ENV_FLAGS)
+    return out if batched else out.view(-1)
 
 
 class _KernelConv(torch.autograd.Function):

@@ -101,6 +101,27 @@ def softmin_online(eps, C_xy, h_y, p=2):
     return out if x.dim() > 2 else out.view(1, -1)
 
 
+class _HipSoftmin:
+    """The soft-min callable handed to ``sinkhorn_loop`` by the HIP drivers: ``softmin(eps, C, h)`` as the reference
+    defines it, plus the fused half-step ``step(...)`` that the loop uses where autograd is off (D <= 3)."""
+
+    def __init__(self, p, multiscale):
+        self.p, self.multiscale = p, multiscale
+
+    def __call__(self, eps, C, h):
+        return softmin_multiscale(eps, C, h, p=self.p) if self.multiscale else softmin_online(eps, C, h, p=self.p)
+
+    def step(self, eps, C, log_w, pot, damping, prev):
+        x, y = C[0], C[1]
+        ranges = C[4] if self.multiscale else None
+        if x.shape[-1] > 3:  # no fused kernel for the generic-dimension path
+            ft = damping * self(eps, C, log_w if pot is None else log_w + pot / eps)
+            return ft if prev is None else 0.5 * (prev + ft)
+        flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
+        out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges)
+        return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
+
+
 def sinkhorn_online(
     a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, cost=None, debias=True,
     potentials=False, **kwargs,
@@ -114,7 +135,7 @@ def sinkhorn_online(
         p = _exponent_of(cost)
     if B == 1:  # like the reference, the single-problem path works on (N,D) clouds
         x, y = x.squeeze(0), y.squeeze(0)
-    softmin = partial(softmin_online, p=p)
+    softmin = _HipSoftmin(p, multiscale=False)
 
     C_xx, C_yy = ((x, x.detach()), (y, y.detach())) if debias else (None, None)
     C_xy, C_yx = ((x, y.detach()), (y, x.detach()))
@@ -188,7 +209,7 @@ def sinkhorn_multiscale(
         cost = cost_formulas[p], cost_routines[p]
     cost_formula, cost_routine = cost[0], cost[1]
     p_kernel = _exponent_of(cost_formula)
-    softmin = partial(softmin_multiscale, p=p_kernel)
+    softmin = _HipSoftmin(p_kernel, multiscale=True)
     extrapolate = partial(extrapolate_samples, softmin=softmin)
 
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 101 /* 0.1.1 */
+#define GLHIP_VERSION 102 /* 0.1.2 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -100,7 +100,23 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
                       void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
- * Gradient of the above with respect to x (the only differentiable argument on the
+ * One fused half-step of the symmetric Sinkhorn iteration (D <= 3):
+ *   t_i   = soft-min(eps, C(x,y), logw + pot / eps)_i          (pot == NULL: logw alone, the initialisation)
+ *   out_i = damping * t_i                                       (prev == NULL)
+ *   out_i = (prev_i + damping * t_i) / 2                        (prev != NULL; out must not alias prev)
+ * Replaces, per soft-min call of the loop at sinkhorn_divergence.py:461-465 and :480-493, the elementwise
+ * ops `log_w + pot/eps`, `damping * (...)` and `0.5 * (f + ft)` that the reference runs as separate torch kernels
+ * (SURVEY §8f, N1).  Same kernels, splits and flags as glhip_softmin_fwd.
+ *   logw (B,M), pot (B,M) or NULL, prev (B,N) or NULL, out (B,N): fp32.
+ */
+int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const float* pot, const float* prev,
+                        float* out, int B, int N, int M, int D, float eps, float damping, int p, int in_dtype,
+                        const int32_t* ranges_i, const int32_t* slices_i,
+                        const int32_t* redranges_j, int n_ranges,
+                        void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * Gradient of glhip_softmin_fwd with respect to x (the only differentiable argument on the
  * reference's path: y and h are detached at sinkhorn_samples.py:392-393,628-651 and
  * sinkhorn_divergence.py:616-623):
  *   grad_x[b,i,:] = grad_out[b,i] * sum_j P_ij * dC/dx(x_i, y_j),

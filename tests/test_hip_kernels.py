@@ -240,3 +240,25 @@ def test_c_abi_error_codes(cuda):
     with pytest.raises(ValueError):
         hip.softmin(-1.0, x, x, torch.zeros(10, device=cuda), p=2)
     assert lib.glhip_version() >= 100
+
+
+@pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (300, 2100, 2, None), (257, 255, 3, 3)])
+@pytest.mark.parametrize("p", [2, 1])
+def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
+    """glhip_sinkhorn_step == (prev + damping * softmin(eps, C, logw + pot/eps)) / 2, and the oracle."""
+    x, y, logw = _clouds(61 + N, N, M, D, B=B)
+    rng = np.random.default_rng(8)
+    pot = (rng.standard_normal(logw.shape) * 0.05).astype(np.float32)
+    prev = rng.standard_normal(x.shape[:-1]).astype(np.float32)
+    eps, damping = 0.01, 0.8
+    xt, yt = _t(x, cuda), _t(y, cuda)
+    unfused = 0.5 * (_t(prev, cuda) + damping * hip.softmin(eps, xt, yt, _t(logw + pot / np.float32(eps), cuda), p=p))
+    fused = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), _t(pot, cuda), _t(prev, cuda), damping, p=p)
+    assert (fused - unfused).abs().max().item() < 2e-6
+    first = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping, p=p)
+    ref = damping * (oracle_c.softmin(eps, x, y, logw, p) if B is None else
+                     np.stack([oracle_c.softmin(eps, x[b], y[b], logw[b], p) for b in range(B)]))
+    assert np.abs(first.cpu().numpy() - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max()
+    with pytest.raises(NotImplementedError):   # no fused kernel beyond D = 3
+        hip.sinkhorn_step(eps, torch.rand(10, 5, device=cuda), torch.rand(12, 5, device=cuda),
+                          torch.zeros(12, device=cuda), None, None, 1.0)

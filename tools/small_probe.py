@@ -1,0 +1,17 @@
+"""Wall-clock of small / medium problems (launch-bound regime)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from geomloss_amd import SamplesLoss
+dev = torch.device("cuda:0")
+for N, D in ((2000, 2), (10000, 3), (30000, 3)):
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.rand(N, D, generator=g).to(dev), torch.rand(N, D, generator=g).to(dev)
+    for backend in ("online", "tensorized", "multiscale"):
+        if backend == "tensorized" and N > 10000: continue
+        L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend=backend)
+        for _ in range(2): L(x, y)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): v = L(x, y)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 5
+        print(f"N={N:6d} D={D} {backend:10s} {t*1e3:8.3f} ms/loss  loss={v.item():.6e}", flush=True)
