@@ -261,4 +261,4 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
     assert np.abs(first.cpu().numpy() - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max()
     with pytest.raises(NotImplementedError):   # no fused kernel beyond D = 3
         hip.sinkhorn_step(eps, torch.rand(10, 5, device=cuda), torch.rand(12, 5, device=cuda),
-                          torch.zeros(12, device=cuda), None, None, 1.0)
+                          torch.zeros(12, device=cuda), None, None, 0.5)
