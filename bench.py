@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=1_000_000, help="N = M of the soft-min workload")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the Sinkhorn wall-clock legs")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU dry run)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dry run of the N>1 path on a 1-GPU box: every rank uses cuda:0 (only with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -140,12 +143,17 @@ def main():
     if world != args.gpus:
         log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from geomloss_amd import hip
     hip.load_library()   # raises if the HIP extension is missing: there is no fallback to time

@@ -34,8 +34,9 @@ int check_launch(const char* what) {
 
 int check_common(const char* fn, const void* x, const void* y, const void* s, int B, int N, int M, int D,
                  int in_dtype, const int32_t* ri, const int32_t* si, const int32_t* rj, int n_ranges) {
-    if (!x || !y || !s) return fail(GLHIP_EINVAL, "%s: NULL input pointer", fn);
     if (B < 0 || N < 0 || M < 0 || D < 1) return fail(GLHIP_EINVAL, "%s: bad sizes B=%d N=%d M=%d D=%d", fn, B, N, M, D);
+    // empty clouds may come with NULL pointers (a torch tensor with no elements has none)
+    if ((!x && (long)B * N > 0) || ((!y || !s) && (long)B * M > 0)) return fail(GLHIP_EINVAL, "%s: NULL input pointer", fn);
     if (in_dtype != GLHIP_F32 && in_dtype != GLHIP_BF16) return fail(GLHIP_EINVAL, "%s: bad in_dtype %d", fn, in_dtype);
     if (n_ranges < 0) return fail(GLHIP_EINVAL, "%s: n_ranges < 0", fn);
     if (n_ranges > 0) {
@@ -338,10 +339,10 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
                       void* stream) {
     int rc = check_common("glhip_softmin_fwd", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
     if (!out) return fail(GLHIP_EINVAL, "glhip_softmin_fwd: NULL out");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_fwd: eps must be > 0");
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd: p must be 1 or 2 (got %d)", p);
-    if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
@@ -357,11 +358,11 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
                         void* workspace, size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_sinkhorn_step", x, y, logw, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
     if (!out) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: NULL out");
     if (out == prev) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: out must not alias prev (updates are simultaneous)");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step: eps must be > 0");
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: p must be 1 or 2 (got %d)", p);
-    if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
@@ -382,10 +383,10 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const floa
                         void* workspace, size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_softmin_bwd_x", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
     if (!out || !grad_out || !grad_x) return fail(GLHIP_EINVAL, "glhip_softmin_bwd_x: NULL out / grad_out / grad_x");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_bwd_x: eps must be > 0");
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_bwd_x: p must be 1 or 2 (got %d)", p);
-    if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
@@ -401,10 +402,10 @@ int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v
                           int flags, void* stream) {
     int rc = check_common("glhip_kernel_conv_fwd", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
     if (!out) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: NULL out");
     if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: bad kind %d", kind);
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: blur must be > 0");
-    if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
@@ -420,10 +421,10 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
                             size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_kernel_conv_bwd_x", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
     if (!g || !grad_x) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: NULL g / grad_x");
     if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: bad kind %d", kind);
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: blur must be > 0");
-    if (B == 0 || N == 0) return GLHIP_OK;
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
@@ -435,11 +436,11 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
 
 int glhip_softmin_dense_fwd(const float* C, const float* h, float* out, int B, int N, int M, float eps,
                             void* stream) {
-    if (!C || !h || !out) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: NULL pointer");
     if (B < 0 || N < 0 || M < 0) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: bad sizes");
+    if (B == 0 || N == 0) return GLHIP_OK;
+    if (!out || ((!C || !h) && M > 0)) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: NULL pointer");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: eps must be > 0");
     if (B > 65535) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_dense_fwd: B=%d exceeds the grid.y limit", B);
-    if (B == 0 || N == 0) return GLHIP_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows_per_block = (kBlock / 64) * kDenseRows;
     dim3 grid((N + rows_per_block - 1) / rows_per_block, B, 1);

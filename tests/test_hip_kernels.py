@@ -262,3 +262,14 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
     with pytest.raises(NotImplementedError):   # no fused kernel beyond D = 3
         hip.sinkhorn_step(eps, torch.rand(10, 5, device=cuda), torch.rand(12, 5, device=cuda),
                           torch.zeros(12, device=cuda), None, None, 0.5)
+
+
+def test_empty_clouds(cuda):
+    """N = 0 returns an empty result; M = 0 is the reduction over the empty set (+inf potential, zero kernel sum)."""
+    x, y0 = torch.rand(5, 3, device=cuda), torch.rand(0, 3, device=cuda)
+    h0 = torch.zeros(0, device=cuda)
+    assert hip.softmin(0.1, y0, x, torch.zeros(5, device=cuda)).shape == (0,)
+    assert torch.isposinf(hip.softmin(0.1, x, y0, h0)).all()
+    assert torch.isposinf(hip.softmin(0.1, x, y0, h0, flags=hip.FLAG_NO_MFMA)).all()
+    assert (hip.kernel_conv("gaussian", x, y0, h0, 0.3) == 0).all()
+    assert (hip.kernel_conv("energy", x, y0, h0, 0.3) == 0).all()
