@@ -1,0 +1,67 @@
+"""Size-independent properties of the drop-in loss on the GPU (HIP backends)."""
+
+import numpy as np
+import pytest
+import torch
+
+from geomloss_amd import SamplesLoss
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(cuda, seed, N, M, D=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, D, generator=g).to(cuda)
+    y = (torch.rand(M, D, generator=g) * 0.7 + 0.2).to(cuda)
+    a = torch.rand(N, generator=g).to(cuda) + 0.1
+    b = torch.rand(M, generator=g).to(cuda) + 0.1
+    return a / a.sum(), x, b / b.sum(), y
+
+
+@pytest.mark.parametrize("loss,kw", [("sinkhorn", dict(p=2, blur=0.05)), ("sinkhorn", dict(p=1, blur=0.1)),
+                                      ("gaussian", dict(blur=0.1)), ("energy", dict())])
+def test_symmetry_and_invariances(cuda, loss, kw):
+    a, x, b, y = _clouds(cuda, 0, 1500, 1700)
+    L = SamplesLoss(loss, backend="online", diameter=2.0, **kw)
+    v = L(a, x, b, y).item()
+    assert abs(L(b, y, a, x).item() - v) < 1e-5 * abs(v)                       # S(a,b) = S(b,a)
+    perm = torch.randperm(1500, generator=torch.Generator().manual_seed(1)).to(cuda)
+    assert abs(L(a[perm], x[perm], b, y).item() - v) < 1e-5 * abs(v)           # relabelling the samples
+    shift = torch.tensor([3.0, -2.0, 1.0], device=cuda)
+    assert abs(L(a, x + shift, b, y + shift).item() - v) < 2e-4 * abs(v)       # translation (inputs re-rounded)
+    assert v > 0
+
+
+def test_loss_of_a_measure_with_itself_vanishes_with_its_gradient(cuda):
+    a, x, _, _ = _clouds(cuda, 2, 2000, 10)
+    x = x.clone().requires_grad_(True)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online")(a, x, a, x.detach().clone())
+    (g,) = torch.autograd.grad(L, [x])
+    assert abs(L.item()) < 1e-6 and g.abs().max().item() < 1e-6
+
+
+def test_batched_loss_equals_per_item_losses(cuda):
+    g = torch.Generator().manual_seed(3)
+    B, N, M = 4, 600, 700
+    x = torch.rand(B, N, 3, generator=g).to(cuda).requires_grad_(True)
+    y = (torch.rand(B, M, 3, generator=g) * 0.5 + 0.4).to(cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")
+    vb = L(x, y)
+    (gb,) = torch.autograd.grad(vb.sum(), [x])
+    for k in range(B):
+        xk = x[k].detach().clone().requires_grad_(True)
+        vk = L(xk, y[k])
+        (gk,) = torch.autograd.grad(vk, [xk])
+        assert abs(vk.item() - vb[k].item()) < 1e-6 * abs(vk.item())
+        assert (gk - gb[k]).abs().max().item() < 1e-6 * gk.abs().max().item() + 1e-9
+
+
+def test_online_and_multiscale_agree_when_the_jump_is_last(cuda):
+    """With diameter = 1 and a tiny cluster scale the coarse level only extrapolates: both backends then solve the
+    same fine problem up to the coarse initialisation."""
+    a, x, b, y = _clouds(cuda, 6, 4000, 4200)
+    x, y = x * 0.5, y * 0.5
+    kw = dict(p=2, blur=0.05, diameter=1.0, scaling=0.8)
+    Lo = SamplesLoss("sinkhorn", backend="online", **kw)(a, x, b, y).item()
+    Lm = SamplesLoss("sinkhorn", backend="multiscale", cluster_scale=0.01, **kw)(a, x, b, y).item()
+    assert abs(Lo - Lm) < 5e-3 * abs(Lo)

@@ -58,6 +58,10 @@ def main():
                     gg = torch.ones(1, N, device=dev)
                     res["conv gauss bwd (mfma)"] = timeit(lambda: hip.kernel_conv_bwd_x_raw(kind, xb, yb, v, gg, 0.05))
                     res["conv gauss bwd valu"] = timeit(lambda: hip.kernel_conv_bwd_x_raw(kind, xb, yb, v, gg, 0.05, flags=2))
+        if "dense" in what and N <= 30000:
+            C = torch.rand(1, N, N, device=dev)
+            tmin, tmed = timeit(lambda: hip.softmin_dense_fwd_raw(C, hb, eps))
+            print(f"N=M={N:>8d} {'dense-matrix softmin':26s} min {tmin*1e3:10.3f} ms  {N*N*4/tmin/1e9:8.1f} GB/s of matrix streamed")
         for k, (tmin, tmed) in res.items():
             print(f"N=M={N:>8d} {k:26s} min {tmin*1e3:10.3f} ms  med {tmed*1e3:10.3f} ms  {pairs/tmin:.3e} pairs/s")
 
