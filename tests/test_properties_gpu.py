@@ -65,3 +65,29 @@ def test_online_and_multiscale_agree_when_the_jump_is_last(cuda):
     Lo = SamplesLoss("sinkhorn", backend="online", **kw)(a, x, b, y).item()
     Lm = SamplesLoss("sinkhorn", backend="multiscale", cluster_scale=0.01, **kw)(a, x, b, y).item()
     assert abs(Lo - Lm) < 5e-3 * abs(Lo)
+
+
+def test_sharded_loss_on_gpu_single_rank(cuda):
+    """ShardedSamplesLoss over the HIP backend (world size 1, gloo): same value / gradient as the plain loss and the
+    global-diameter collective path (diameter=None) runs on GPU tensors."""
+    import os
+    import torch.distributed as dist
+    from geomloss_amd.distributed import ShardedSamplesLoss
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(9)
+        x = torch.rand(3, 500, 3, generator=g).to(cuda).bfloat16().requires_grad_(True)
+        y = (torch.rand(3, 600, 3, generator=g) * 0.6 + 0.3).to(cuda).bfloat16()
+        base = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online")
+        ref = base(x, y)
+        tot = ShardedSamplesLoss(base, "sum")(x, y)
+        vec = ShardedSamplesLoss(base, "none")(x, y)
+        assert abs(tot.item() - ref.sum().item()) < 1e-6 * abs(tot.item())
+        assert (vec - ref).abs().max().item() < 1e-7
+        (g1,) = torch.autograd.grad(tot, [x])
+        assert torch.isfinite(g1.float()).all() and g1.float().abs().max() > 0
+    finally:
+        dist.destroy_process_group()
