@@ -13,6 +13,7 @@ The Sinkhorn loop itself lives in :mod:`geomloss_amd.sinkhorn_divergence`; the k
 through :mod:`geomloss_amd.hip`.
 """
 
+import os
 from functools import partial
 
 import numpy as np
@@ -122,12 +123,26 @@ class _HipSoftmin:
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
 
+# hipGraph mode for the launch-bound regime (small clouds): the whole autograd-free annealing loop of the online
+# backend — 4 fused launches per temperature — is captured once per (shapes, schedule) and replayed as ONE graph launch.
+# Opt-in (GEOMLOSS_HIP_GRAPH=1 or set_graph_mode(True)) and only when `diameter` is given, because the temperatures are
+# kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
+_graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
+_graphs = hip.GraphCache()
+
+
+def set_graph_mode(enabled):
+    global _graph_mode
+    _graph_mode = bool(enabled)
+
+
 def sinkhorn_online(
     a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, cost=None, debias=True,
     potentials=False, **kwargs,
 ):
     """Sinkhorn divergence with O(N+M) memory; a (B,N), x (B,N,D), b (B,M), y (B,M,D) on a GPU."""
     B = x.shape[0]
+    diameter_given = diameter is not None
     a, b = _fp32_weights(a, b)
     if cost is not None:
         if B > 1:
@@ -142,10 +157,42 @@ def sinkhorn_online(
 
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
 
-    f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
-        softmin, log_weights(a), log_weights(b), C_xx, C_yy, C_xy, C_yx, eps_list, rho, debias=debias
-    )
+    a_log, b_log = log_weights(a), log_weights(b)
+    if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3:
+        f_aa, g_bb, g_ab, f_ba = _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias)
+    else:
+        f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
+            softmin, a_log, b_log, C_xx, C_yy, C_xy, C_yx, eps_list, rho, debias=debias
+        )
     return sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, batch=True, debias=debias, potentials=potentials)
+
+
+def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
+    """`sinkhorn_loop` with its autograd-free part replayed from a hipGraph; the last, differentiable half-steps
+    (sinkhorn_divergence.py:612-623) run eagerly, exactly as in the loop."""
+    from .sinkhorn_divergence import dampening
+
+    def annealing(xs, ys, al, bl):
+        Cxx, Cyy = ((xs, xs), (ys, ys)) if debias else (None, None)
+        out = sinkhorn_loop(softmin, al, bl, Cxx, Cyy, (xs, ys), (ys, xs), eps_list, rho, debias=debias,
+                            last_extrapolation=False)
+        return out
+
+    key = (tuple(x.shape), tuple(y.shape), x.dtype, x.device.index, tuple(float(e) for e in eps_list), rho,
+           softmin.p, debias)
+    was_enabled = torch.is_grad_enabled()
+    f_aa, g_bb, g_ab, f_ba = _graphs.run(key, annealing, (x, y, a_log, b_log))
+    torch.autograd.set_grad_enabled(True)   # what sinkhorn_loop leaves behind (reference behaviour)
+    eps = eps_list[-1]
+    damping = dampening(eps, rho)
+    xd, yd = x.detach(), y.detach()
+    f_ba, g_ab = (damping * softmin(eps, (x, yd), (b_log + g_ab / eps).detach()),
+                  damping * softmin(eps, (y, xd), (a_log + f_ba / eps).detach()))
+    if debias:
+        f_aa = damping * softmin(eps, (x, xd), (a_log + f_aa / eps).detach())
+        g_bb = damping * softmin(eps, (y, yd), (b_log + g_bb / eps).detach())
+    del was_enabled
+    return f_aa, g_bb, g_ab, f_ba
 
 
 # ==============================================================================

@@ -15,3 +15,14 @@ for N, D in ((2000, 2), (10000, 3), (30000, 3)):
         for _ in range(5): v = L(x, y)
         torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 5
         print(f"N={N:6d} D={D} {backend:10s} {t*1e3:8.3f} ms/loss  loss={v.item():.6e}", flush=True)
+    # hipGraph mode (needs a fixed diameter)
+    from geomloss_amd import sinkhorn_samples as ss
+    for mode in (False, True):
+        ss.set_graph_mode(mode)
+        L = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")
+        for _ in range(3): L(x, y)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): v = L(x, y)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+        print(f"N={N:6d} D={D} online diameter=1.8 graph={mode!s:5s} {t*1e3:8.3f} ms/loss  loss={v.item():.6e}", flush=True)
+    ss.set_graph_mode(False)
