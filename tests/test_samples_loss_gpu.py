@@ -189,3 +189,26 @@ def test_full_size_block_sparse_equals_dense_when_everything_is_kept(cuda):
     fd = hip.softmin(0.01, xs, xs, h)
     fs = hip.softmin(0.01, xs, xs, h, ranges=rg)
     assert (fd - fs).abs().max().item() < 1.5e-6
+
+
+@pytest.mark.parametrize("kw", [
+    dict(p=1, blur=0.1, scaling=0.7),                       # block-sparse VALU kernels (p = 1)
+    dict(p=2, blur=0.05, scaling=0.7, reach=0.3),           # unbalanced: damping + the reference's shadowed-eps quirk
+    dict(p=2, blur=0.05, scaling=0.7, debias=False),        # raw entropic cost: 2 soft-mins per step
+    dict(p=2, blur=0.05, scaling=0.7, truncate=2),          # tighter truncation
+    dict(p=2, blur=0.05, scaling=0.7, cluster_scale=0.2),   # user voxel size (few, large clusters)
+])
+def test_multiscale_variants_match_two_scale_oracle(cuda, kw):
+    N, M = 2600, 2400
+    x, y = _two_clouds(21, N, M, kind="shifted")
+    rng = np.random.default_rng(22)
+    a = rng.random(N) + 0.2
+    b = rng.random(M) + 0.2
+    a, b = a / a.sum(), b / b.sum()
+    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True, **kw)
+    at, bt = torch.from_numpy(a).float().to(cuda), torch.from_numpy(b).float().to(cuda)
+    xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
+    L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(at, xt, bt, yt)
+    assert abs(L.item() - ref) / abs(ref) < 1e-4, (L.item(), ref, info["jumps"], info["kept_fraction"])
+    (gx,) = torch.autograd.grad(L, [xt])
+    assert torch.isfinite(gx).all()
