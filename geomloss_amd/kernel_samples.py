@@ -72,44 +72,48 @@ class _LazyKernel:
         return _LazyKernel(self.name, self.y, self.x, self.blur, None if self.ranges is None else self.ranges.t())
 
 
-def kernel_loss(
-    α, x, β, y, blur=0.05, kernel=None, name=None, potentials=False, use_keops=False,
-    ranges_xx=None, ranges_yy=None, ranges_xy=None, **kwargs,
-):
-    """Kernel norm or its potentials (``:92-146``).  ``use_keops=True`` selects the matrix-free HIP path
-    (the keyword keeps the reference's name; no KeOps is involved)."""
-    if use_keops:
+def _matvec(K, v):
+    """K @ v for a dense (..., N, M) matrix or a :class:`_LazyKernel`, with v of shape (..., M)."""
+    return (K @ v.unsqueeze(-1)).squeeze(-1)
+
+
+def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
+    """(K_xx, K_yy, K_xy).  Symmetric blocks differentiate through their first argument only, with a doubled
+    gradient (kernel_samples.py:117-125)."""
+    r_xx, r_yy, r_xy = ranges
+    if lazy:
         if kernel is not None:
             raise NotImplementedError(
                 "geomloss_amd: custom 'kernel' functions need dense matrices; use backend='tensorized'."
             )
         if name not in kernel_routines:
             raise KeyError(name)
-        K_xx = _LazyKernel(name, double_grad(x), x.detach(), blur, ranges_xx)
-        K_yy = _LazyKernel(name, double_grad(y), y.detach(), blur, ranges_yy)
-        K_xy = _LazyKernel(name, x, y, blur, ranges_xy)
+        build = lambda u, w, r: _LazyKernel(name, u, w, blur, r)  # noqa: E731
     else:
-        if kernel is None:
-            kernel = kernel_routines[name]
-        K_xx = kernel(double_grad(x), x.detach(), blur=blur)
-        K_yy = kernel(double_grad(y), y.detach(), blur=blur)
-        K_xy = kernel(x, y, blur=blur)
+        dense = kernel_routines[name] if kernel is None else kernel
+        build = lambda u, w, r: dense(u, w, blur=blur)  # noqa: E731
+    return build(double_grad(x), x.detach(), r_xx), build(double_grad(y), y.detach(), r_yy), build(x, y, r_xy)
 
-    a_x = (K_xx @ α.detach().unsqueeze(-1)).squeeze(-1)
-    b_y = (K_yy @ β.detach().unsqueeze(-1)).squeeze(-1)
-    b_x = (K_xy @ β.unsqueeze(-1)).squeeze(-1)
+
+def kernel_loss(
+    α, x, β, y, blur=0.05, kernel=None, name=None, potentials=False, use_keops=False,
+    ranges_xx=None, ranges_yy=None, ranges_xy=None, **kwargs,
+):
+    """Kernel norm 1/2 <α-β, k*(α-β)> or its potentials (``:92-146``).  ``use_keops=True`` selects the matrix-free
+    HIP path (the keyword keeps the reference's name; no KeOps is involved)."""
+    K_xx, K_yy, K_xy = _kernel_operators(x, y, blur, kernel, name, use_keops, (ranges_xx, ranges_yy, ranges_xy))
+
+    a_x = _matvec(K_xx, α.detach())  # (k * α)(x_i)
+    b_y = _matvec(K_yy, β.detach())  # (k * β)(y_j)
+    b_x = _matvec(K_xy, β)           # (k * β)(x_i)
 
     if potentials:
-        Kt = K_xy.t() if use_keops else K_xy.transpose(-1, -2)
-        a_y = (Kt @ α.unsqueeze(-1)).squeeze(-1)
-        return a_x - b_x, b_y - a_y
+        K_yx = K_xy.t() if use_keops else K_xy.transpose(-1, -2)
+        return a_x - b_x, b_y - _matvec(K_yx, α)
 
     batch = x.dim() > 2
-    return (
-        0.5 * scal(double_grad(α), a_x, batch=batch)
-        + 0.5 * scal(double_grad(β), b_y, batch=batch)
-        - scal(α, b_x, batch=batch)
-    )
+    self_terms = scal(double_grad(α), a_x, batch=batch) + scal(double_grad(β), b_y, batch=batch)
+    return 0.5 * self_terms - scal(α, b_x, batch=batch)
 
 
 kernel_tensorized = partial(kernel_loss, use_keops=False)
