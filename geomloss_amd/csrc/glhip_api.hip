@@ -80,11 +80,13 @@ void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_range
 // 2 row tiles per wavefront (128 rows per workgroup): 84-126 VGPRs -> 4-5 waves/SIMD; measured equal to 4 tiles at
 // N=M=1e6 and 11-16 % faster on mid-size, batched and block-sparse problems.
 constexpr int kFwdRT = 2;
-template <int D, typename T, int RT, bool XDL = false>
-void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
-                         const Scratch& sc, hipStream_t st) {
+// p = 2 forward on the matrix cores; same partial format / merge kernel as the VALU op.
+//   XDL = false: fp32 MFMA (glhip_softmin_mfma.h), 4 waves.   XDL = true: bf16x3 (glhip_softmin_xdl.h), NW waves.
+template <int D, typename T, int RT, bool XDL, int NW>
+void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                            const Scratch& sc, hipStream_t st) {
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
-    constexpr int kRowsPerBlock = 64 * RT;
+    constexpr int kRowsPerBlock = NW * 16 * RT;
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
     const long per_split = (long)B * N * 2 * sizeof(float);
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
@@ -93,17 +95,29 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
     if (n_ranges > 0) {
-        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, true, RT, NW>), dim3(n_ranges, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
         else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     } else {
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
         else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
+}
+
+template <int D, typename T, int RT, bool XDL>
+void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                         const Scratch& sc, hipStream_t st) {
+    // Workgroup height of the bf16x3 kernel.  8 wavefronts (256 rows) halve the per-pair cost of staging a column tile
+    // (each tile is packed into bf16x3 operands once per workgroup): +4 % at N = 1e6; but they halve the number of
+    // workgroups, which costs 15-20 % on mid-size (1e5), batched 4096-point and block-sparse problems.  Measured.
+    if (XDL && n_ranges == 0 && (long)B * N >= 400000 && N >= 100000)
+        launch_softmin_mfma_nw<D, T, RT, XDL, 8>(prm, rg, n_ranges, B, N, M, sc, st);
+    else
+        launch_softmin_mfma_nw<D, T, RT, XDL, 4>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
 // weighted-sum matrix-core kernels (glhip_wsum_mfma.h); MergeOp is the VALU operator with the same partial format

@@ -58,11 +58,12 @@ __device__ __forceinline__ f32x4 mfma_x(const uint4& a, const uint4& b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa.v, pb.v, c, 0, 0, 0);
 }
 
-template <int D, typename T, bool SPARSE, int RT>
-__global__ void __launch_bounds__(kBlock)
+template <int D, typename T, bool SPARSE, int RT, int NW = 4>
+__global__ void __launch_bounds__(NW * 64)
 softmin_fwd_xdl_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerWave = RT * 16;
-    constexpr int kRowsPerBlock = 4 * kRowsPerWave;
+    constexpr int kRowsPerBlock = NW * kRowsPerWave;
+    constexpr int kThreads = NW * 64;
     __shared__ uint4 tileX[(kTileX / 16) * 64];   // [column group][lane = kblock*16 + j]
 
     const int tid = threadIdx.x;
@@ -108,7 +109,7 @@ softmin_fwd_xdl_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
                 const int n = min(kTileX, je - j0);
                 const int npad = (n + 63) & ~63;
                 __syncthreads();
-                for (int t = tid; t < npad; t += kBlock) {
+                for (int t = tid; t < npad; t += kThreads) {
                     float rec[4] = {0.f, 0.f, 0.f, kNegBig};
                     if (t < n) {
                         float yj[D];
