@@ -94,6 +94,19 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
+    sp.xcd_grid_x = 0;
+    if (XDL && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
+        // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
+        sp.n_splits = 8;
+        sp.xcd_grid_x = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+        const long total = (long)sp.xcd_grid_x * B * 8;
+        if (total < (1L << 31)) {
+            hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+            return;
+        }
+        sp.xcd_grid_x = 0;
+    }
     if (n_ranges > 0) {
         if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, true, RT, NW>), dim3(n_ranges, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
         else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
@@ -133,6 +146,7 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * MergeOp::kPartial;
+    sp.xcd_grid_x = 0;
     if (n_ranges > 0) {
         hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, true>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
@@ -341,8 +355,12 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     if (B <= 0 || N <= 0 || M <= 0 || D < 1 || D > 3) return 0;   // the generic-D kernels do not split
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
     const int ns = choose_splits(row_blocks, M, n_ranges, 1L << 30);
-    if (ns < 2) return 0;
-    return (size_t)ns * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);   // widest partial: D + 1 floats
+    size_t bytes = ns < 2 ? 0 : (size_t)ns * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);   // widest partial: D + 1 floats
+    if (n_ranges == 0 && M >= 65536) {   // the XCD-aware forward wants 8 splits of 2 floats per row
+        const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * 2 * sizeof(float);
+        bytes = bytes > xcd ? bytes : xcd;
+    }
+    return bytes;
 }
 
 const char* glhip_last_error(void) { return g_err; }

@@ -31,20 +31,40 @@ struct SplitInfo {
     int n_splits;       // 1 = no split
     float* workspace;   // [n_splits][B*N][kPartial] floats
     long split_stride;  // floats between consecutive splits = B*N*kPartial
+    int xcd_grid_x;     // > 0: 1-D XCD-aware grid (see workgroup_coords); value = number of row blocks per batch item
 };
+
+// Logical (row block, batch item, column split) of this workgroup.  Plain mode: the 3-D grid.  XCD-aware mode
+// (dense kernels with n_splits == 8): a 1-D grid whose linear id is split-major modulo 8.  The dispatcher places
+// workgroup b on XCD b % 8 (observed behaviour, used for speed only), so XCD k only ever streams the k-th eighth
+// of the column cloud: at M = 1e6 that is 2 MB of points + dual values, resident in the XCD's 4 MB L2 instead of
+// being re-fetched through the fabric by every row block.
+__device__ __forceinline__ void workgroup_coords(const SplitInfo& sp, int& bx, int& by, int& bz) {
+    if (sp.xcd_grid_x > 0) {
+        const int lid = blockIdx.x;
+        bz = lid % sp.n_splits;
+        const int rest = lid / sp.n_splits;
+        bx = rest % sp.xcd_grid_x;
+        by = rest / sp.xcd_grid_x;
+    } else {
+        bx = blockIdx.x;
+        by = blockIdx.y;
+        bz = blockIdx.z;
+    }
+}
 
 // rows [row_begin,row_end) and CSR slice [q_begin,q_end) of workgroup blockIdx.x
 template <bool SPARSE>
 __device__ __forceinline__ void block_extent(const Ranges& rg, int N, int rows_per_pass, int& row_begin,
-                                             int& row_end, int& q_begin, int& q_end) {
+                                             int& row_end, int& q_begin, int& q_end, int bx = blockIdx.x) {
     if (SPARSE) {
-        const int k = blockIdx.x;
+        const int k = bx;
         row_begin = rg.ranges_i[2 * k];
         row_end = rg.ranges_i[2 * k + 1];
         q_begin = (k == 0) ? 0 : rg.slices_i[k - 1];
         q_end = rg.slices_i[k];
     } else {
-        row_begin = blockIdx.x * rows_per_pass;
+        row_begin = bx * rows_per_pass;
         row_end = min(N, row_begin + rows_per_pass);
         q_begin = 0;
         q_end = 1;
@@ -159,6 +179,7 @@ static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges
     sp.n_splits = (allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
     sp.workspace = static_cast<float*>(workspace);
     sp.split_stride = (long)B * N * Op::kPartial;
+    sp.xcd_grid_x = 0;
     if (n_ranges > 0) {
         dim3 grid(n_ranges, 1, sp.n_splits);
         hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rg, N, M, sp);
