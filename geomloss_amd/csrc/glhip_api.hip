@@ -147,6 +147,17 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * MergeOp::kPartial;
     sp.xcd_grid_x = 0;
+    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD (workgroup_coords)
+        sp.n_splits = 8;
+        sp.xcd_grid_x = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+        const long total = (long)sp.xcd_grid_x * B * 8;
+        if (total < (1L << 31)) {
+            hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, false>), dim3((unsigned)total, 1, 1), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(sp.xcd_grid_x, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+            return;
+        }
+        sp.xcd_grid_x = 0;
+    }
     if (n_ranges > 0) {
         hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, true>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
@@ -356,8 +367,8 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
     const int ns = choose_splits(row_blocks, M, n_ranges, 1L << 30);
     size_t bytes = ns < 2 ? 0 : (size_t)ns * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);   // widest partial: D + 1 floats
-    if (n_ranges == 0 && M >= 65536) {   // the XCD-aware forward wants 8 splits of 2 floats per row
-        const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * 2 * sizeof(float);
+    if (n_ranges == 0 && M >= 65536) {   // the XCD-aware grids want 8 splits (widest partial: D + 1 floats per row)
+        const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
         bytes = bytes > xcd ? bytes : xcd;
     }
     return bytes;

@@ -68,14 +68,14 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int split = blockIdx.z;
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
     const int ns = sp.n_splits;
     const int lk = lane >> 4;
     const int lj = lane & 15;
 
     int row_begin, row_end, q_begin, q_end;
-    block_extent<SPARSE>(rg, N, kMfmaRowsPerBlock, row_begin, row_end, q_begin, q_end);
+    block_extent<SPARSE>(rg, N, kMfmaRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
 
     for (int row0 = row_begin; row0 < row_end; row0 += kMfmaRowsPerBlock) {
         float centre[D];
