@@ -11,6 +11,7 @@
 #include "glhip_softmin_mfma.h"
 #include "glhip_wsum_mfma.h"
 #include "glhip_softmin_xdl.h"
+#include "glhip_softmin_x32.h"
 
 using namespace glhip;
 
@@ -81,12 +82,23 @@ void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_range
 // N=M=1e6 and 11-16 % faster on mid-size, batched and block-sparse problems.
 constexpr int kFwdRT = 2;
 // p = 2 forward on the matrix cores; same partial format / merge kernel as the VALU op.
-//   XDL = false: fp32 MFMA (glhip_softmin_mfma.h), 4 waves.   XDL = true: bf16x3 (glhip_softmin_xdl.h), NW waves.
-template <int D, typename T, int RT, bool XDL, int NW>
+//   KIND 0: fp32 MFMA (glhip_softmin_mfma.h), 4 waves.   KIND 1: bf16x3 on 16x16x32 MFMAs (glhip_softmin_xdl.h).
+//   KIND 2: bf16x3 on 32x32x16 MFMAs, transposed blocks (glhip_softmin_x32.h) — the default.
+enum { FWD_F32 = 0, FWD_XDL16 = 1, FWD_X32 = 2 };
+
+template <int D, typename T, int KIND, int NW, bool SPARSE>
+void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp) {
+    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+    else if (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+    else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+}
+
+template <int D, typename T, int KIND, int NW>
 void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                             const Scratch& sc, hipStream_t st) {
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
-    constexpr int kRowsPerBlock = NW * 16 * RT;
+    constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
+    static_assert(kFwdRT == 2, "row tiling of the forward kernels");
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
     const long per_split = (long)B * N * 2 * sizeof(float);
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
@@ -95,42 +107,42 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
     sp.xcd_grid_x = 0;
-    if (XDL && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
+    if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
         sp.n_splits = 8;
         sp.xcd_grid_x = (N + kRowsPerBlock - 1) / kRowsPerBlock;
         const long total = (long)sp.xcd_grid_x * B * 8;
         if (total < (1L << 31)) {
-            hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
             return;
         }
         sp.xcd_grid_x = 0;
     }
     if (n_ranges > 0) {
-        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, true, RT, NW>), dim3(n_ranges, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
-        else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, true, RT>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        launch_fwd_kernel<D, T, KIND, NW, true>(dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     } else {
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        if (XDL) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
-        else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, false, RT>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        launch_fwd_kernel<D, T, KIND, NW, false>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
 }
 
-template <int D, typename T, int RT, bool XDL>
+template <int D, typename T, int KIND>
 void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                          const Scratch& sc, hipStream_t st) {
-    // Workgroup height of the bf16x3 kernel.  8 wavefronts (256 rows) halve the per-pair cost of staging a column tile
+    // Workgroup height of the bf16x3 kernels.  8 wavefronts (256 rows) halve the per-pair cost of staging a column tile
     // (each tile is packed into bf16x3 operands once per workgroup): +4 % at N = 1e6; but they halve the number of
     // workgroups, which costs 15-20 % on mid-size (1e5), batched 4096-point and block-sparse problems.  Measured.
-    if (XDL && n_ranges == 0 && (long)B * N >= 400000 && N >= 100000)
-        launch_softmin_mfma_nw<D, T, RT, XDL, 8>(prm, rg, n_ranges, B, N, M, sc, st);
+    if (KIND == FWD_F32)
+        launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (n_ranges == 0 && (long)B * N >= 400000 && N >= 100000)
+        launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 8>(prm, rg, n_ranges, B, N, M, sc, st);
     else
-        launch_softmin_mfma_nw<D, T, RT, XDL, 4>(prm, rg, n_ranges, B, N, M, sc, st);
+        launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 4>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
 // weighted-sum matrix-core kernels (glhip_wsum_mfma.h); MergeOp is the VALU operator with the same partial format
@@ -181,11 +193,12 @@ void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int 
 
 template <int D, bool BWD, typename T>
 void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
-                      bool direct, bool mfma, bool xdl, const Scratch& sc, hipStream_t st) {
+                      bool direct, bool mfma, int kind, const Scratch& sc, hipStream_t st) {
     if (p == 1) launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (direct) launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (!BWD && mfma && xdl) launch_softmin_mfma<D, T, kFwdRT, true>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (!BWD && mfma) launch_softmin_mfma<D, T, kFwdRT, false>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma && kind == FWD_X32) launch_softmin_mfma<D, T, FWD_X32>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma && kind == FWD_XDL16) launch_softmin_mfma<D, T, FWD_XDL16>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (!BWD && mfma) launch_softmin_mfma<D, T, FWD_F32>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (BWD && mfma) launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, st);
     else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
@@ -223,7 +236,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.alpha = step.alpha;
         prm.beta = step.beta;
         const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
-        const bool xdl = (flags & GLHIP_FLAG_F32_MFMA) == 0;
+        const int xdl = (flags & GLHIP_FLAG_F32_MFMA) ? FWD_F32 : (flags & GLHIP_FLAG_XDL16) ? FWD_XDL16 : FWD_X32;
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);

@@ -1,0 +1,231 @@
+// glhip_softmin_x32.h — soft-min forward (p = 2, D <= 3), bf16x3 exponents on v_mfma_f32_32x32x16_bf16.
+//
+// Same arithmetic as glhip_softmin_xdl.h (every fp32 operand = 3 exact bf16 pieces, 8 products per coordinate),
+// different tiling, chosen from measurements on MI355X (tools/ubench/overlap.hip, profiles/r01_ubench_pipes.txt):
+// beside exp2-bound VALU work a 16x16x32 MFMA still costs ~6 issue cycles per 256 exponents, a 32x32x16 MFMA
+// costs ~0 per 1024 — the matrix pipe time itself hides completely.  So:
+//   * one MFMA pair (K = 2 x 16) produces a 32 x 32 block of exponents;
+//   * the block is TRANSPOSED with respect to the 16x16 kernel: the MFMA "A" rows are 32 columns y_j (from LDS),
+//     the MFMA "B" columns are 32 rows x_i (in registers).  In the result lane l owns row i = l % 32 and its 16
+//     registers are 16 different columns, so the row sum is 15 adds inside the lane + one add into ONE running
+//     register (not a 4- or 16-register tile), the running max is one value per lane, and the final merge of a
+//     row is a single cross-half shuffle;
+//   * the running max enters through the K slots instead of the accumulator input: K layout (4 blocks of 8 slots,
+//     lanes 0-31 hold blocks 0 / 2, lanes 32-63 blocks 1 / 3 of the two MFMAs)
+//       block d < D : y side [y1,y2,y1,y3,y1,y2,y3,y2]   x side [a1,a1,a2,a1,a3,a2,a2,a3]
+//       block 3     : y side [H1,H2,H3, 1, 1, 1, 0, 0]   x side [ 1, 1, 1,n1,n2,n3, 0, 0]     n = -running max
+//     and C = 0 (an inline constant: no accumulator-input registers at all).
+// Lazy max, speculative tile pass, tile-end check, exact redo, column splits and the merge are as in the 16x16 kernel.
+#pragma once
+
+#include "glhip_softmin_xdl.h"
+
+namespace glhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma_x32(const uint4& a, const uint4& b, const f32x16& c) {
+    Pack16 pa, pb;
+    pa.u = a;
+    pb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.v, pb.v, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 pack_h1(float h) {    // [H1,H2,H3,1,1,1,0,0]
+    uint32_t p1, p2, p3;
+    split3(h, p1, p2, p3);
+    return uint4{p1 | (p2 << 16), p3 | 0x3F800000u, 0x3F803F80u, 0u};
+}
+// x-side block 3, [1,1,1,n1,n2,n3,0,0] with n = -m
+__device__ __forceinline__ uint4 pack_negmax(float m) {
+    uint32_t p1, p2, p3;
+    split3(-m, p1, p2, p3);
+    return uint4{0x3F803F80u, 0x3F80u | (p1 << 16), p2 | (p3 << 16), 0u};
+}
+
+__device__ __forceinline__ float max16(const f32x16& v) {
+    const float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+    const float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float sum_exp2_16(const f32x16& v) {
+    float e[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = fast_exp2(v[k]);
+    return (((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]))) +
+           (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
+}
+__device__ __forceinline__ float sum_exp2_16(const f32x16& v, float m) {
+    float e[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = fast_exp2(v[k] - m);
+    return (((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]))) +
+           (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
+}
+
+template <int D, typename T, bool SPARSE, int RT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    constexpr int kRowsPerWave = RT * 32;
+    constexpr int kRowsPerBlock = NW * kRowsPerWave;
+    constexpr int kThreads = NW * 64;
+    __shared__ uint4 tileX[kTileX * 4];   // [column group of 32][K block][column]: one 16-byte record per (column, K block)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
+    const int ns = sp.n_splits;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int rec0 = half * 32 + l31;     // this lane's record inside a column group: K block `half` (+2 for the 2nd MFMA)
+
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint4 kOnes = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // [1,1,1,0,...]: block 3 with n = 0
+
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
+        float centre[D];
+        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+
+        const int wave_row0 = row0 + wave * kRowsPerWave;
+        uint4 Xlo[RT], Xhi[RT];
+        float m[RT], ssum[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int i = min(wave_row0 + rt * 32 + l31, row_end - 1);
+            float xi[D];
+            load_point<D, T>(prm.x, (long)b * N + i, xi);
+            float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < D; ++d) a[d] = (xi[d] - centre[d]) * prm.s2;
+            const uint4 z = uint4{0u, 0u, 0u, 0u};
+            const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : z, p2 = (D > 2) ? pack_a(a[2]) : z;
+            Xlo[rt] = half ? p1 : p0;
+            Xhi[rt] = half ? kOnes : p2;
+            m[rt] = kMinusHuge;
+            ssum[rt] = 0.f;
+        }
+        const bool wave_active = wave_row0 < row_end;
+        bool first_group = true;
+
+        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
+            int js, je;
+            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            for (int j0 = js; j0 < je; j0 += kTileX) {
+                const int n = min(kTileX, je - j0);
+                const int npad = (n + 31) & ~31;
+                __syncthreads();
+                for (int t = tid; t < npad; t += kThreads) {
+                    float rec[4] = {0.f, 0.f, 0.f, kNegBig};
+                    if (t < n) {
+                        float yj[D];
+                        load_point<D, T>(prm.y, (long)b * M + j0 + t, yj);
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            rec[d] = yj[d] - centre[d];
+                            n2 = __builtin_fmaf(rec[d], rec[d], n2);
+                        }
+                        rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, (long)b * M + j0 + t) * kLog2e);
+                    }
+                    uint4* base = &tileX[(t >> 5) * 128 + (t & 31)];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
+                    base[96] = pack_h1(rec[3]);
+                }
+                __syncthreads();
+                if (!wave_active) continue;
+
+                const int nG = npad / 32;
+                int G0 = 0;
+                if (first_group) {   // exact maximum over the first 32 columns
+                    const uint4 ya = tileX[rec0], yb = tileX[64 + rec0];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x16 u = mfma_x32(ya, Xlo[rt], zero16);
+                        u = mfma_x32(yb, Xhi[rt], u);
+                        float um = max16(u);
+                        um = fmaxf(um, __shfl_xor(um, 32, 64));
+                        um = fmaxf(um, kMinusHuge);
+                        m[rt] = um;
+                        ssum[rt] = sum_exp2_16(u, um);
+                        if (half) Xhi[rt] = pack_negmax(um);
+                    }
+                    first_group = false;
+                    G0 = 1;
+                }
+
+                float stmp[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
+#pragma unroll 2
+                for (int G = G0; G < nG; ++G) {
+                    const uint4 ya = tileX[G * 128 + rec0], yb = tileX[G * 128 + 64 + rec0];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x16 d = mfma_x32(ya, Xlo[rt], zero16);
+                        d = mfma_x32(yb, Xhi[rt], d);
+                        stmp[rt] += sum_exp2_16(d);
+                    }
+                }
+                float smax = stmp[0];
+#pragma unroll
+                for (int rt = 1; rt < RT; ++rt) smax = fmaxf(smax, stmp[rt]);
+                if (__any(!(smax < kSumThr))) {
+                    // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
+                    for (int G = G0; G < nG; ++G) {
+                        const uint4 ya = tileX[G * 128 + rec0], yb = tileX[G * 128 + 64 + rec0];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            f32x16 u = mfma_x32(ya, Xlo[rt], zero16);
+                            u = mfma_x32(yb, half ? kOnes : Xhi[rt], u);
+                            float um = max16(u);
+                            um = fmaxf(um, __shfl_xor(um, 32, 64));
+                            const float mnew = fmaxf(m[rt], um);
+                            ssum[rt] = ssum[rt] * fast_exp2(m[rt] - mnew) + sum_exp2_16(u, mnew);
+                            m[rt] = mnew;
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        if (half) Xhi[rt] = pack_negmax(m[rt]);
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
+                }
+            }
+        }
+
+        if (wave_active) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // both halves carry the same max
+                const int i = wave_row0 + rt * 32 + l31;
+                if (half == 0 && i < row_end) {
+                    float xi[D];
+                    load_point<D, T>(prm.x, (long)b * N + i, xi);
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const float xt = xi[d] - centre[d];
+                        n2 = __builtin_fmaf(xt, xt, n2);
+                    }
+                    const float mtot = __builtin_fmaf(-0.5f * prm.s2, n2, m[rt]);   // r_i + m
+                    if (ns == 1) {
+                        prm.out[(long)b * N + i] = finish_value(prm, (long)b * N + i, mtot + fast_log2(s));
+                    } else {
+                        float* dst = sp.workspace + split * sp.split_stride + ((long)b * N + i) * 2;
+                        dst[0] = mtot;
+                        dst[1] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace glhip

@@ -34,6 +34,9 @@ def main():
         pairs = float(N) * N
         what = args.what.split(",")
         res = {}
+        if "fwd" in what:
+            res["softmin p2 (bf16x3 32x32x16)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2), reps=5)
+            res["softmin p2 (bf16x3 16x16x32)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=16), reps=5)
         if "softmin" in what:
             res["softmin p2 (xdl bf16x3)"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2))
             res["softmin p2 f32 mfma"] = timeit(lambda: hip.softmin_fwd_raw(xb, yb, hb, eps, 2, flags=8))

@@ -7,8 +7,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>   // bit0: f32 mfma, bit1: exp work, bit2: bf16 mfma instead of f32, bit3: plain fma work instead of exp
-__global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
+__global__ void __launch_bounds__(256) k(float* out, int iters, float seed, unsigned long long* clk) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     f32x4 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{seed, seed, seed, seed};
     float a = seed * lane, b = seed + lane;
@@ -41,16 +42,24 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
     for (int i = 0; i < 16; ++i) s0 += e[i];
     for (int i = 0; i < 4; ++i) s1 += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
     out[blockIdx.x * 256 + threadIdx.x] = s0 + s1;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
+static unsigned long long* g_clk = nullptr;
 template <int MODE> float run(float* d, int blocks, int iters) {
+    if (!g_clk) hipMalloc(&g_clk, 16);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.5f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.5f, g_clk);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.5f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.5f, g_clk);
     hipEventRecord(b); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b); return ms;
+    float ms; hipEventElapsedTime(&ms, a, b);
+    unsigned long long h[2]; hipMemcpy(h, g_clk, 16, hipMemcpyDeviceToHost);
+    // clock64 = s_memtime (shader-clock domain), wall_clock64 = s_memrealtime (constant 100 MHz)
+    printf("    [mode %2d] %8.3f ms | workgroup 0: clock64 %llu ticks, wall %llu ticks (%.3f ms) -> clock64 rate %.1f MHz\n", MODE, ms,
+           h[0], h[1], h[1] / 1e5, h[0] / (h[1] / 100.0));
+    return ms;
 }
 
 int main(int argc, char** argv) {
