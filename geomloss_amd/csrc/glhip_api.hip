@@ -88,7 +88,7 @@ enum { FWD_F32 = 0, FWD_XDL16 = 1, FWD_X32 = 2 };
 
 template <int D, typename T, int KIND, int NW, bool SPARSE>
 void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp) {
-    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
     else if (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
     else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
@@ -113,7 +113,17 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         sp.xcd_grid_x = (N + kRowsPerBlock - 1) / kRowsPerBlock;
         const long total = (long)sp.xcd_grid_x * B * 8;
         if (total < (1L << 31)) {
-            launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
+            // room behind the partials for the packed column records?  then split the columns once per launch
+            const size_t part_bytes = (((size_t)8 * per_split) + 255) & ~(size_t)255;
+            PackedCols pk;
+            pk.stride = (long)((M + 31) / 32) * 128;
+            pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+            if (KIND == FWD_X32 && sc.bytes >= part_bytes + (size_t)B * pk.stride * sizeof(uint4)) {
+                hipLaunchKernelGGL((pack_columns_kernel<D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+                hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+            } else {
+                launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
+            }
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
             return;
         }
@@ -383,6 +393,10 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     if (n_ranges == 0 && M >= 65536) {   // the XCD-aware grids want 8 splits (widest partial: D + 1 floats per row)
         const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
         bytes = bytes > xcd ? bytes : xcd;
+        // forward: 8 splits of 2 floats per row + the packed column records (64 bytes per column, glhip_softmin_x32.h)
+        const size_t fwd = (size_t)8 * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 +
+                           (size_t)B * (size_t)((M + 31) / 32) * 128 * 16;
+        bytes = bytes > fwd ? bytes : fwd;
     }
     return bytes;
 }

@@ -63,9 +63,51 @@ __device__ __forceinline__ float sum_exp2_16(const f32x16& v, float m) {
            (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
 }
 
-template <int D, typename T, bool SPARSE, int RT, int NW>
+// One column of the cost matrix as the four 16-byte MFMA records of the layout above (coordinates relative to `centre`).
+template <int D, typename T>
+__device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long col, bool valid, const float (&centre)[D],
+                                            uint4* base /* record of K block 0; blocks are 32 records apart */) {
+    float rec[4] = {0.f, 0.f, 0.f, kNegBig};
+    if (valid) {
+        float yj[D];
+        load_point<D, T>(prm.y, col, yj);
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            rec[d] = yj[d] - centre[d];
+            n2 = __builtin_fmaf(rec[d], rec[d], n2);
+        }
+        rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, col) * kLog2e);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
+    base[96] = pack_h1(rec[3]);
+}
+
+// Packed column records for a whole launch (PRE mode of the kernel below): large dense problems split every column
+// once here instead of once per 256-row workgroup.  One centre per batch item (its first row): for unsorted clouds a
+// workgroup's own first row is an equally arbitrary point, so nothing is lost; block-sparse (sorted) launches keep
+// the per-workgroup centre and pack on the fly.
+struct PackedCols {
+    uint4* rec;        // [B][ceil(M/32)][4 K blocks][32 columns]
+    long stride;       // records per batch item = ceil(M/32) * 128
+};
+
+template <int D, typename T>
+__global__ void __launch_bounds__(kBlock)
+pack_columns_kernel(SoftminParams<T> prm, int N, int M, PackedCols pk) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= ((M + 31) & ~31)) return;
+    float centre[D];
+    load_point<D, T>(prm.x, (long)b * N, centre);
+    pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31));
+}
+
+template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64)
-softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
+    static_assert(!(PRE && SPARSE), "pre-packed columns are a dense-mode feature");
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
@@ -73,7 +115,7 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the loop control on the scalar unit
     int bx, b, split;
     workgroup_coords(sp, bx, b, split);
     const int ns = sp.n_splits;
@@ -89,7 +131,7 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
-        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+        load_point<D, T>(prm.x, (long)b * N + (PRE ? 0 : row0), centre);
 
         const int wave_row0 = row0 + wave * kRowsPerWave;
         uint4 Xlo[RT], Xhi[RT];
@@ -114,28 +156,36 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
 
         for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
             int js, je;
-            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            if (PRE) {   // split boundaries on whole 32-column groups of the packed layout
+                const int len = (((M + ns - 1) / ns) + 31) & ~31;
+                js = min(M, split * len);
+                je = min(M, js + len);
+            } else {
+                column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            }
+            // PRE: the records of the next tile are fetched into registers before the current tile is consumed
+            constexpr int kPer = PRE ? (kTileX * 4) / kThreads : 1;
+            uint4 pre[kPer];
+            auto fetch = [&](int j0) {
+                const int cnt = ((min(kTileX, je - j0) + 31) & ~31) * 4;
+                const uint4* src = pk.rec + b * pk.stride + (long)(j0 >> 5) * 128;
+#pragma unroll
+                for (int k = 0; k < kPer; ++k)
+                    if (tid + k * kThreads < cnt) pre[k] = src[tid + k * kThreads];
+            };
+            if (PRE && js < je) fetch(js);
             for (int j0 = js; j0 < je; j0 += kTileX) {
                 const int n = min(kTileX, je - j0);
                 const int npad = (n + 31) & ~31;
                 __syncthreads();
-                for (int t = tid; t < npad; t += kThreads) {
-                    float rec[4] = {0.f, 0.f, 0.f, kNegBig};
-                    if (t < n) {
-                        float yj[D];
-                        load_point<D, T>(prm.y, (long)b * M + j0 + t, yj);
-                        float n2 = 0.f;
+                if (PRE) {
 #pragma unroll
-                        for (int d = 0; d < D; ++d) {
-                            rec[d] = yj[d] - centre[d];
-                            n2 = __builtin_fmaf(rec[d], rec[d], n2);
-                        }
-                        rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, (long)b * M + j0 + t) * kLog2e);
-                    }
-                    uint4* base = &tileX[(t >> 5) * 128 + (t & 31)];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
-                    base[96] = pack_h1(rec[3]);
+                    for (int k = 0; k < kPer; ++k)
+                        if (tid + k * kThreads < npad * 4) tileX[tid + k * kThreads] = pre[k];
+                    if (j0 + kTileX < je) fetch(j0 + kTileX);
+                } else {
+                    for (int t = tid; t < npad; t += kThreads)
+                        pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)]);
                 }
                 __syncthreads();
                 if (!wave_active) continue;

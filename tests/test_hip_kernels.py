@@ -44,11 +44,29 @@ def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
     x, y, h = _clouds(N + M + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, p)
     # every code path of the forward kernel: matrix-core / VALU exponents, with / without column splits
-    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, 8 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
+    for flags in (0, hip.FLAG_F32_MFMA, hip.FLAG_XDL16, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_F32_MFMA | hip.FLAG_NO_SPLIT,
+                  hip.FLAG_XDL16 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags  # diam^2 <= D on the unit cube
     out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
     assert relerr(out_d, ref) < 2e-6
+
+
+@pytest.mark.parametrize("N,M,D", [(700, 70001, 3), (300, 66000, 2)])
+def test_softmin_fwd_many_columns(cuda, N, M, D):
+    """M >= 65536 selects the 8-split XCD-aware grid and, for the default kernel, the pre-packed column records."""
+    eps = 0.05**2
+    x, y, h = _clouds(N + D, N, M, D)
+    ref = oracle_c.softmin(eps, x, y, h, 2)
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT):
+        out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, flags=flags).cpu().numpy()
+        assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags
+    # sorted clouds, batched, through the fused half-step entry point
+    xb, yb, hb = _clouds(5, 130, M, D, B=2)
+    lw = np.full((2, M), -np.log(M), np.float32)
+    ref_b = np.stack([oracle_c.softmin(eps, xb[k], yb[k], lw[k] + hb[k] / eps, 2) for k in range(2)])
+    out_b = hip.sinkhorn_step(eps, _t(xb, cuda), _t(yb, cuda), _t(lw, cuda), _t(hb, cuda), None, 1.0).cpu().numpy()
+    assert np.abs(out_b - ref_b).max() < 4e-7 * D + 2e-6 * np.abs(ref_b).max()
 
 
 @pytest.mark.parametrize("N,M,D", [(300, 257, 3), (1030, 1100, 2), (200, 300, 1)])
