@@ -37,10 +37,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-# Issue-bound model of the default kernel (softmin_fwd_xdl_kernel), from the micro-benchmark in
-# profiles/r01_ubench_pipes.txt: per 64 pairs one v_exp_f32 (8.5 cycles), a quarter of a
-# v_mfma_f32_16x16x32_bf16 (17.5 / 4) and one v_add_f32 (2.5), which do not overlap on a SIMD.
-ISSUE_CYCLES_PER_64_PAIRS = 8.5 + 17.5 / 4 + 2.5
+# Issue-bound model of the default kernel (softmin_fwd_x32_kernel), from tools/ubench/overlap.hip
+# (profiles/r01_ubench_pipes.txt): the VALU stream of 1024 pairs is 16 v_exp_f32 + 16 v_add_f32 = 200 SIMD cycles at
+# the nominal 2.4 GHz with the 32x32x16 MFMA hidden beside it (12.5 cycles per 64 pairs); the kernel's whole inner
+# loop (chained MFMA pair + that stream, no LDS) measures 13.5.
+ISSUE_CYCLES_PER_64_PAIRS = 200.0 / 16
+LOOP_CYCLES_PER_64_PAIRS = 13.5
 ISSUE_CEILING_PAIRS_PER_S = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_64_PAIRS
 
 
@@ -227,12 +229,15 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "model": "dense-equivalent: 4 algorithmic bytes per pair (SURVEY §8d); the kernel is issue-bound (exp2 + MFMA), "
                          "frac > 1 means it beats what any kernel streaming the fp32 cost matrix could reach",
-                "kernel": "softmin_fwd_xdl_kernel<3,float,false,2> (+ merge_kernel when the columns are split)",
+                "kernel": "pack_columns_kernel + softmin_fwd_x32_kernel<3,float,false,1,8,true> + merge_kernel (one "
+                          "glhip_softmin_fwd call; the x32 kernel is > 99.9 % of it)",
                 "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
                 "compulsory_bytes_per_launch": compulsory, "compulsory_GBs": compulsory / (kernel_ms * 1e-3) / 1e9,
                 "issue_model_frac": kernel_pairs_s / ISSUE_CEILING_PAIRS_PER_S,
-                "issue_model": f"{ISSUE_CYCLES_PER_64_PAIRS:.2f} SIMD cycles per 64 pairs (v_exp_f32 8.5 + bf16 MFMA 17.5/4 + "
-                               f"v_add_f32 2.5, measured, non-overlapping) -> {ISSUE_CEILING_PAIRS_PER_S:.3g} pairs/s at 2.4 GHz",
+                "issue_model": f"{ISSUE_CYCLES_PER_64_PAIRS:.2f} SIMD cycles per 64 pairs = the exp2 + add stream alone (16 v_exp_f32 + "
+                               f"16 v_add_f32 per 1024 pairs, micro-benchmarked, MFMA hidden) -> {ISSUE_CEILING_PAIRS_PER_S:.3g} pairs/s at "
+                               f"2.4 GHz; the bare inner loop (chained 32x32x16 MFMA pair + that stream) measures "
+                               f"{LOOP_CYCLES_PER_64_PAIRS} cycles -> {256 * 4 * 2.4e9 * 64 / LOOP_CYCLES_PER_64_PAIRS:.3g} pairs/s",
             },
         }
         if world == 1 and not args.no_extras:

@@ -2,6 +2,7 @@
 // scale factors, kernel selection, asynchronous launch.  gfx950 only.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -107,19 +108,30 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
     sp.xcd_grid_x = 0;
+
+    // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
+    // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
+    PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    auto plan_pre = [&](int ns) {
+        const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
+        if (KIND != FWD_X32 || n_ranges > 0 || !sc.ws || (double)B * N * M < 5e8) return false;
+        if (sc.bytes < part_bytes + (size_t)B * pk.stride * sizeof(uint4)) return false;
+        pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+        return true;
+    };
+    auto pack = [&]() {
+        hipLaunchKernelGGL((pack_columns_kernel<D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+    };
+
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
-        sp.n_splits = 8;
-        sp.xcd_grid_x = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        const long total = (long)sp.xcd_grid_x * B * 8;
+        const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+        const long total = (long)gx * B * 8;
         if (total < (1L << 31)) {
-            // room behind the partials for the packed column records?  then split the columns once per launch
-            const size_t part_bytes = (((size_t)8 * per_split) + 255) & ~(size_t)255;
-            PackedCols pk;
-            pk.stride = (long)((M + 31) / 32) * 128;
-            pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
-            if (KIND == FWD_X32 && sc.bytes >= part_bytes + (size_t)B * pk.stride * sizeof(uint4)) {
-                hipLaunchKernelGGL((pack_columns_kernel<D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+            sp.n_splits = 8;
+            sp.xcd_grid_x = gx;
+            if (plan_pre(8)) {
+                pack();
                 hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
             } else {
                 launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
@@ -127,7 +139,6 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
             return;
         }
-        sp.xcd_grid_x = 0;
     }
     if (n_ranges > 0) {
         launch_fwd_kernel<D, T, KIND, NW, true>(dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp);
@@ -135,7 +146,12 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     } else {
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        launch_fwd_kernel<D, T, KIND, NW, false>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
+        if (plan_pre(sp.n_splits)) {
+            pack();
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+        } else {
+            launch_fwd_kernel<D, T, KIND, NW, false>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
+        }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
@@ -144,12 +160,13 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
 template <int D, typename T, int KIND>
 void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                          const Scratch& sc, hipStream_t st) {
-    // Workgroup height of the bf16x3 kernels.  8 wavefronts (256 rows) halve the per-pair cost of staging a column tile
-    // (each tile is packed into bf16x3 operands once per workgroup): +4 % at N = 1e6; but they halve the number of
-    // workgroups, which costs 15-20 % on mid-size (1e5), batched 4096-point and block-sparse problems.  Measured.
+    // Workgroup height of the bf16x3 kernels: 8 wavefronts (256 rows) for dense launches big enough to run with
+    // pre-packed columns (1-4 % faster than 4 there, measured from B x N = 256 x 4096 to 1 x 1e6); 4 wavefronts when
+    // every workgroup packs its own tiles (small and block-sparse launches), where more, smaller workgroups win.
+    static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
     if (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (n_ranges == 0 && (long)B * N >= 400000 && N >= 100000)
+    else if (forced_nw ? forced_nw == 8 : (n_ranges == 0 && (double)B * N * M >= 5e8 && (long)B * N >= 32768))
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 8>(prm, rg, n_ranges, B, N, M, sc, st);
     else
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 4>(prm, rg, n_ranges, B, N, M, sc, st);
@@ -393,8 +410,14 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     if (n_ranges == 0 && M >= 65536) {   // the XCD-aware grids want 8 splits (widest partial: D + 1 floats per row)
         const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
         bytes = bytes > xcd ? bytes : xcd;
-        // forward: 8 splits of 2 floats per row + the packed column records (64 bytes per column, glhip_softmin_x32.h)
-        const size_t fwd = (size_t)8 * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 +
+    }
+    if (n_ranges == 0) {
+        // forward: up to max(ns, 8) splits of 2 floats per row + the packed column records (64 bytes per column,
+        // glhip_softmin_x32.h)
+        const int ns128 = choose_splits((long)B * ((N + 127) / 128), M, 0, 1L << 30), ns256 = choose_splits((long)B * ((N + 255) / 256), M, 0, 1L << 30);
+        int nf = ns128 > ns256 ? ns128 : ns256;
+        nf = (M >= 65536) ? (nf > 8 ? nf : 8) : (nf < 2 ? 0 : nf);
+        const size_t fwd = (size_t)nf * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 +
                            (size_t)B * (size_t)((M + 31) / 32) * 128 * 16;
         bytes = bytes > fwd ? bytes : fwd;
     }

@@ -104,6 +104,17 @@ pack_columns_kernel(SoftminParams<T> prm, int N, int M, PackedCols pk) {
     pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31));
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // register-friendly 16-byte value (HIP's uint4 is a struct)
+
+template <int PER, int THREADS>
+__device__ __forceinline__ void fetch_records(u32x4 (&pre)[PER], const uint4* src, int cnt, int tid) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = tid + k * THREADS;
+        pre[k] = *reinterpret_cast<const u32x4*>(src + (t < cnt ? t : 0));
+    }
+}
+
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
@@ -165,15 +176,8 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
             }
             // PRE: the records of the next tile are fetched into registers before the current tile is consumed
             constexpr int kPer = PRE ? (kTileX * 4) / kThreads : 1;
-            uint4 pre[kPer];
-            auto fetch = [&](int j0) {
-                const int cnt = ((min(kTileX, je - j0) + 31) & ~31) * 4;
-                const uint4* src = pk.rec + b * pk.stride + (long)(j0 >> 5) * 128;
-#pragma unroll
-                for (int k = 0; k < kPer; ++k)
-                    if (tid + k * kThreads < cnt) pre[k] = src[tid + k * kThreads];
-            };
-            if (PRE && js < je) fetch(js);
+            u32x4 pre[kPer];
+            if (PRE && js < je) fetch_records<kPer, kThreads>(pre, pk.rec + b * pk.stride + (long)(js >> 5) * 128, ((min(kTileX, je - js) + 31) & ~31) * 4, tid);
             for (int j0 = js; j0 < je; j0 += kTileX) {
                 const int n = min(kTileX, je - j0);
                 const int npad = (n + 31) & ~31;
@@ -181,8 +185,10 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
                 if (PRE) {
 #pragma unroll
                     for (int k = 0; k < kPer; ++k)
-                        if (tid + k * kThreads < npad * 4) tileX[tid + k * kThreads] = pre[k];
-                    if (j0 + kTileX < je) fetch(j0 + kTileX);
+                        if (tid + k * kThreads < npad * 4) *reinterpret_cast<u32x4*>(&tileX[tid + k * kThreads]) = pre[k];
+                    if (j0 + kTileX < je)
+                        fetch_records<kPer, kThreads>(pre, pk.rec + b * pk.stride + (long)((j0 + kTileX) >> 5) * 128,
+                                                      ((min(kTileX, je - j0 - kTileX) + 31) & ~31) * 4, tid);
                 } else {
                     for (int t = tid; t < npad; t += kThreads)
                         pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)]);

@@ -25,6 +25,15 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
+    if "batched" in args.what:
+        for (B, N, dt) in ((256, 4096, torch.bfloat16), (256, 4096, torch.float32), (64, 16384, torch.float32), (1, 50000, torch.float32)):
+            torch.manual_seed(0)
+            x, y = torch.rand(B, N, 3, device=dev).to(dt), torch.rand(B, N, 3, device=dev).to(dt)
+            h = torch.full((B, N), -float(torch.log(torch.tensor(float(N)))), device=dev)
+            for fl, nm in ((0, "32x32x16"), (16, "16x16x32")):
+                t = timeit(lambda: hip.softmin_fwd_raw(x, y, h, 0.05**2, 2, flags=fl), reps=5)
+                print("B=%d N=M=%d %s softmin fwd %s: %.3f ms  %.3e pairs/s" % (B, N, str(dt)[6:], nm, t[0] * 1e3, B * N * N / t[0]))
+        return
     for N in [int(s) for s in args.sizes.split(",")]:
         torch.manual_seed(0)
         x, y = torch.rand(N, 3, device=dev), torch.rand(N, 3, device=dev)

@@ -93,6 +93,39 @@ template <int KE, int KA, int DEP, int MF> void run(int wps, int iters) {
            ms * 2.4e6 / (iters * 4.0 * wps), (double)h / (iters * 4.0));
 }
 
+// The inner loop of softmin_fwd_x32_kernel without its LDS traffic: a chained pair of 32x32x16 MFMAs (C = 0, then
+// accumulate), then exp2 of the 16 results of the PREVIOUS pair and the 16 adds of the row sum.
+__global__ void __launch_bounds__(256) kloop(float* out, int iters, float seed, unsigned long long* clk) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 ab, bb, ab2, bb2;
+    for (int i = 0; i < 8; ++i) { ab[i] = (short)(lane + i); bb[i] = (short)(lane * 3 + i); ab2[i] = (short)(lane * 5 + i); bb2[i] = (short)(lane * 7 + i); }
+    f32x16 zero;
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+    float s = seed;
+    for (int it = 0; it < iters; ++it) {
+        ab[0] = (short)it;   // keep the MFMAs inside the loop
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, zero, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab2, bb2, d, 0, 0, 0);
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(d[i]);
+        s += (((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]))) + (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void runloop(int wps, int iters) {
+    const int blocks = 256 * wps;
+    hipLaunchKernelGGL(kloop, dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
+    (void)hipDeviceSynchronize();
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(kloop, dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    printf("  x32 loop (2 chained mfma32x32x16 + 16 exp + 16 add) : %6.1f cyc/1024 pairs/SIMD = %5.2f cyc per 64 pairs (wall@2.4GHz)\n",
+           ms * 2.4e6 / ((double)iters * wps), ms * 2.4e6 / ((double)iters * wps) / 16.0);
+}
+
 template <int KE, int KA> void run32(int wps, int iters) {
     const int blocks = 256 * wps;
     hipLaunchKernelGGL((k32<KE, KA>), dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
@@ -119,6 +152,7 @@ int main(int argc, char** argv) {
     run<4, 4, 0, 1>(wps, iters);
     run<4, 0, 1, 1>(wps, iters); run<4, 0, 1, 0>(wps, iters);
     run32<0, 0>(wps, iters); run32<4, 0>(wps, iters); run32<8, 0>(wps, iters); run32<16, 0>(wps, iters);
+    runloop(wps, iters);
     run32<0, 8>(wps, iters); run32<0, 16>(wps, iters); run32<8, 8>(wps, iters); run32<16, 16>(wps, iters);
     return 0;
 }
