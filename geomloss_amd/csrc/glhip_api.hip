@@ -112,15 +112,17 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
     PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);   // either layout fits
     auto plan_pre = [&](int ns) {
         const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
-        if (KIND != FWD_X32 || n_ranges > 0 || !sc.ws || (double)B * N * M < 5e8) return false;
-        if (sc.bytes < part_bytes + (size_t)B * pk.stride * sizeof(uint4)) return false;
+        if (KIND != FWD_X32 || !sc.ws || (double)B * N * M < 5e8) return false;
+        if (sc.bytes < part_bytes + packed_bytes) return false;
         pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
         return true;
     };
     auto pack = [&]() {
-        hipLaunchKernelGGL((pack_columns_kernel<D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+        if (n_ranges > 0) hipLaunchKernelGGL((pack_columns_kernel<D, T, false>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+        else hipLaunchKernelGGL((pack_columns_kernel<D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
     };
 
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
@@ -141,7 +143,12 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         }
     }
     if (n_ranges > 0) {
-        launch_fwd_kernel<D, T, KIND, NW, true>(dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp);
+        if (plan_pre(sp.n_splits)) {
+            pack();
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(n_ranges, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+        } else {
+            launch_fwd_kernel<D, T, KIND, NW, true>(dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp);
+        }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     } else {
@@ -160,13 +167,15 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
 template <int D, typename T, int KIND>
 void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                          const Scratch& sc, hipStream_t st) {
-    // Workgroup height of the bf16x3 kernels: 8 wavefronts (256 rows) for dense launches big enough to run with
-    // pre-packed columns (1-4 % faster than 4 there, measured from B x N = 256 x 4096 to 1 x 1e6); 4 wavefronts when
-    // every workgroup packs its own tiles (small and block-sparse launches), where more, smaller workgroups win.
+    // Workgroup height of the bf16x3 kernels: 8 wavefronts (256 rows per pass) for launches big enough to run with
+    // pre-packed columns — dense (1-4 % faster than 4 there, measured from B x N = 256 x 4096 to 1 x 1e6) and
+    // block-sparse with row blocks of a few hundred points (multiscale at 1e6: 0.27 vs 0.30 s); 4 wavefronts when
+    // every workgroup packs its own tiles or the row blocks are small, where more, smaller workgroups win.
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
     if (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (forced_nw ? forced_nw == 8 : (n_ranges == 0 && (double)B * N * M >= 5e8 && (long)B * N >= 32768))
+    else if (forced_nw ? forced_nw == 8
+                       : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 8>(prm, rg, n_ranges, B, N, M, sc, st);
     else
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 4>(prm, rg, n_ranges, B, N, M, sc, st);
@@ -411,14 +420,17 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         const size_t xcd = (size_t)8 * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
         bytes = bytes > xcd ? bytes : xcd;
     }
-    if (n_ranges == 0) {
-        // forward: up to max(ns, 8) splits of 2 floats per row + the packed column records (64 bytes per column,
-        // glhip_softmin_x32.h)
-        const int ns128 = choose_splits((long)B * ((N + 127) / 128), M, 0, 1L << 30), ns256 = choose_splits((long)B * ((N + 255) / 256), M, 0, 1L << 30);
-        int nf = ns128 > ns256 ? ns128 : ns256;
-        nf = (M >= 65536) ? (nf > 8 ? nf : 8) : (nf < 2 ? 0 : nf);
-        const size_t fwd = (size_t)nf * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 +
-                           (size_t)B * (size_t)((M + 31) / 32) * 128 * 16;
+    {
+        // forward: its split partials (2 floats per row) + the packed column records (64 bytes per column, glhip_softmin_x32.h)
+        int nf;
+        if (n_ranges > 0) {
+            nf = ns;
+        } else {
+            const int ns128 = choose_splits((long)B * ((N + 127) / 128), M, 0, 1L << 30), ns256 = choose_splits((long)B * ((N + 255) / 256), M, 0, 1L << 30);
+            nf = ns128 > ns256 ? ns128 : ns256;
+            if (M >= 65536 && nf < 8) nf = 8;
+        }
+        const size_t fwd = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 + (size_t)B * (size_t)((M + 31) / 32) * 2048;
         bytes = bytes > fwd ? bytes : fwd;
     }
     return bytes;

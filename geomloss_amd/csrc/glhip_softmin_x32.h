@@ -63,10 +63,11 @@ __device__ __forceinline__ float sum_exp2_16(const f32x16& v, float m) {
            (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
 }
 
-// One column of the cost matrix as the four 16-byte MFMA records of the layout above (coordinates relative to `centre`).
+// One column of the cost matrix as the four 16-byte MFMA records of the layout above (coordinates relative to
+// `centre`), written `stride` records apart starting at `base` (K block 0).
 template <int D, typename T>
 __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long col, bool valid, const float (&centre)[D],
-                                            uint4* base /* record of K block 0; blocks are 32 records apart */) {
+                                            uint4* base, int stride) {
     float rec[4] = {0.f, 0.f, 0.f, kNegBig};
     if (valid) {
         float yj[D];
@@ -80,48 +81,93 @@ __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long co
         rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, col) * kLog2e);
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
-    base[96] = pack_h1(rec[3]);
+    for (int d = 0; d < 3; ++d) base[d * stride] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
+    base[3 * stride] = pack_h1(rec[3]);
 }
 
-// Packed column records for a whole launch (PRE mode of the kernel below): large dense problems split every column
-// once here instead of once per 256-row workgroup.  One centre per batch item (its first row): for unsorted clouds a
-// workgroup's own first row is an equally arbitrary point, so nothing is lost; block-sparse (sorted) launches keep
-// the per-workgroup centre and pack on the fly.
+// Packed column records for a whole launch (PRE mode of the kernel below): launches with enough work split every
+// column once here instead of once per row pass of every workgroup.  One centre per batch item (its first row): for
+// unsorted clouds a workgroup's own first row is an equally arbitrary point; for cluster-sorted clouds (block-sparse
+// mode) the per-workgroup centre of the on-the-fly path is more accurate, the global one has the accuracy of the
+// dense launches (absolute error of a potential ~ 2^-23 diam^2, independent of eps).
 struct PackedCols {
-    uint4* rec;        // [B][ceil(M/32)][4 K blocks][32 columns]
-    long stride;       // records per batch item = ceil(M/32) * 128
+    uint4* rec;     // dense launches (GROUPED): [B][ceil(M/32)][4 K blocks][32 columns] — the LDS tile layout, so a tile
+                    //   (which starts on a group boundary there) is staged by a linear, fully coalesced copy;
+                    // block-sparse launches: [M][4 K blocks] — tiles start at arbitrary columns
+    long stride;    // GROUPED: records per batch item = ceil(M/32) * 128
 };
 
-template <int D, typename T>
+template <int D, typename T, bool GROUPED>
 __global__ void __launch_bounds__(kBlock)
 pack_columns_kernel(SoftminParams<T> prm, int N, int M, PackedCols pk) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= ((M + 31) & ~31)) return;
+    if (j >= (GROUPED ? ((M + 31) & ~31) : M)) return;
     float centre[D];
     load_point<D, T>(prm.x, (long)b * N, centre);
-    pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31));
+    if (GROUPED) pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31), 32);
+    else pack_column<D, T>(prm, (long)b * M + j, true, centre, pk.rec + ((long)b * M + j) * 4, 1);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // register-friendly 16-byte value (HIP's uint4 is a struct)
 
-template <int PER, int THREADS>
-__device__ __forceinline__ void fetch_records(u32x4 (&pre)[PER], const uint4* src, int cnt, int tid) {
+// registers <- this thread's share of the next tile.  GROUPED: records r = tid, tid + THREADS, ... of the contiguous
+// run `src` (cnt records); otherwise the 4 records of columns t = tid, tid + THREADS, ... (n real columns at `src`).
+template <int PER, int THREADS, bool GROUPED>
+__device__ __forceinline__ void fetch_records(u32x4 (&pre)[PER], const uint4* src, int n, int tid) {
+    if (GROUPED) {
+        const int cnt = ((n + 31) & ~31) * 4;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int t = tid + k * THREADS;
-        pre[k] = *reinterpret_cast<const u32x4*>(src + (t < cnt ? t : 0));
+        for (int k = 0; k < PER; ++k) {
+            const int r = tid + k * THREADS;
+            pre[k] = *reinterpret_cast<const u32x4*>(src + (r < cnt ? r : 0));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) {
+            const int t = tid + k * THREADS;
+            const u32x4* col = reinterpret_cast<const u32x4*>(src + (long)(t < n ? t : 0) * 4);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) pre[k * 4 + kb] = col[kb];
+        }
+    }
+}
+
+// the next tile of columns of a workgroup: interval q of the block-sparse ranges (or the split's single interval),
+// columns [j0, min(j0 + kTileX, je))
+struct TileCursor {
+    int q, j0, je;
+};
+
+template <bool SPARSE, bool ALIGN32>
+__device__ __forceinline__ void open_interval(const Ranges& rg, int M, int q_end, int split, int ns, TileCursor& c) {
+    // skip empty intervals; c.q == q_end (or beyond) means "no more tiles"
+    while (c.q < q_end) {
+        int js, je;
+        if (!SPARSE && ALIGN32) {   // split boundaries on whole 32-column groups
+            const int len = (((M + ns - 1) / ns) + 31) & ~31;
+            js = min(M, split * len);
+            je = min(M, js + len);
+        } else {
+            column_interval<SPARSE>(rg, M, c.q, split, ns, js, je);
+        }
+        if (js < je) {
+            c.j0 = js;
+            c.je = je;
+            return;
+        }
+        c.q += SPARSE ? ns : 1;
     }
 }
 
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
-    static_assert(!(PRE && SPARSE), "pre-packed columns are a dense-mode feature");
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
+    constexpr int kPer = (kTileX * 4) / kThreads;   // PRE: records one thread moves per tile
+    static_assert((kTileX * 4) % kThreads == 0, "tile / workgroup shape");
     __shared__ uint4 tileX[kTileX * 4];   // [column group of 32][K block][column]: one 16-byte record per (column, K block)
 
     const int tid = threadIdx.x;
@@ -165,34 +211,59 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
         const bool wave_active = wave_row0 < row_end;
         bool first_group = true;
 
-        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
-            int js, je;
-            if (PRE) {   // split boundaries on whole 32-column groups of the packed layout
-                const int len = (((M + ns - 1) / ns) + 31) & ~31;
-                js = min(M, split * len);
-                je = min(M, js + len);
-            } else {
-                column_interval<SPARSE>(rg, M, q, split, ns, js, je);
-            }
-            // PRE: the records of the next tile are fetched into registers before the current tile is consumed
-            constexpr int kPer = PRE ? (kTileX * 4) / kThreads : 1;
-            u32x4 pre[kPer];
-            if (PRE && js < je) fetch_records<kPer, kThreads>(pre, pk.rec + b * pk.stride + (long)(js >> 5) * 128, ((min(kTileX, je - js) + 31) & ~31) * 4, tid);
-            for (int j0 = js; j0 < je; j0 += kTileX) {
-                const int n = min(kTileX, je - j0);
+        // PRE: the records of the next tile are fetched into registers while the current tile is consumed
+        u32x4 pre[kPer];
+        const uint4 nh = pack_h1(kNegBig);
+        const u32x4 neutral_h = u32x4{nh.x, nh.y, nh.z, nh.w};
+        auto tile_src = [&](int j0) {   // first record of the tile starting at column j0 in the packed buffer
+            return SPARSE ? pk.rec + ((long)b * M + j0) * 4 : pk.rec + b * pk.stride + (long)(j0 >> 5) * 128;
+        };
+        TileCursor cur;
+        cur.q = q_begin + (SPARSE ? split : 0);
+        cur.j0 = cur.je = 0;
+        open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, cur);
+        if (PRE && cur.q < q_end)
+            fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(cur.j0), min(kTileX, cur.je - cur.j0), tid);
+
+        while (cur.q < q_end) {
+            {
+                const int j0 = cur.j0;
+                const int n = min(kTileX, cur.je - j0);
                 const int npad = (n + 31) & ~31;
+                TileCursor nxt = cur;   // the tile after this one
+                nxt.j0 += kTileX;
+                if (nxt.j0 >= nxt.je) {
+                    nxt.q += SPARSE ? ns : 1;
+                    open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, nxt);
+                }
                 __syncthreads();
-                if (PRE) {
+                if (PRE && !SPARSE) {
 #pragma unroll
-                    for (int k = 0; k < kPer; ++k)
-                        if (tid + k * kThreads < npad * 4) *reinterpret_cast<u32x4*>(&tileX[tid + k * kThreads]) = pre[k];
-                    if (j0 + kTileX < je)
-                        fetch_records<kPer, kThreads>(pre, pk.rec + b * pk.stride + (long)((j0 + kTileX) >> 5) * 128,
-                                                      ((min(kTileX, je - j0 - kTileX) + 31) & ~31) * 4, tid);
+                    for (int k = 0; k < kPer; ++k) {
+                        const int r = tid + k * kThreads;
+                        if (r < npad * 4) *reinterpret_cast<u32x4*>(&tileX[r]) = pre[k];
+                    }
+                } else if (PRE) {
+#pragma unroll
+                    for (int k = 0; k < kPer / 4; ++k) {
+                        const int t = tid + k * kThreads;
+                        if (t < npad) {
+                            u32x4* dst = reinterpret_cast<u32x4*>(&tileX[(t >> 5) * 128 + (t & 31)]);
+                            const bool real = t < n;
+#pragma unroll
+                            for (int kb = 0; kb < 3; ++kb) dst[kb * 32] = real ? pre[k * 4 + kb] : u32x4{0u, 0u, 0u, 0u};
+                            dst[96] = real ? pre[k * 4 + 3] : neutral_h;
+                        }
+                    }
+                }
+                if (PRE) {
+                    if (nxt.q < q_end)
+                        fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(nxt.j0), min(kTileX, nxt.je - nxt.j0), tid);
                 } else {
                     for (int t = tid; t < npad; t += kThreads)
-                        pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)]);
+                        pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)], 32);
                 }
+                cur = nxt;
                 __syncthreads();
                 if (!wave_active) continue;
 
@@ -218,7 +289,6 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
                 float stmp[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
-#pragma unroll 2
                 for (int G = G0; G < nG; ++G) {
                     const uint4 ya = tileX[G * 128 + rec0], yb = tileX[G * 128 + 64 + rec0];
 #pragma unroll
