@@ -13,6 +13,7 @@
 #include "glhip_wsum_mfma.h"
 #include "glhip_softmin_xdl.h"
 #include "glhip_softmin_x32.h"
+#include "glhip_wsum_x32.h"
 
 using namespace glhip;
 
@@ -181,12 +182,31 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 4>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
-// weighted-sum matrix-core kernels (glhip_wsum_mfma.h); MergeOp is the VALU operator with the same partial format
+// weighted-sum matrix-core kernels; MergeOp is the VALU operator with the same partial format.
+//   x32 = true: glhip_wsum_x32.h (32x32x16 MFMAs, pre-packed columns when the launch is big enough) — the default;
+//   x32 = false: glhip_wsum_mfma.h (16x16x32 MFMAs, GLHIP_FLAG_XDL16).
+// The 32x32x16 form pays for the one-component reduction (gaussian product: 1 exp2 + 1 fma per pair, 89.8 vs 92.4 ms
+// at 1e6).  With D + 1 accumulators per row it needs 64 accumulator registers per lane and its bare loop measures
+// 22.8 cycles per 64 pairs (tools/ubench/overlap.hip) — what the 16x16x32 kernel already delivers end to end
+// (23.3); the shipped x32 gradient kernels were slower (188 vs 148 ms), so the gradients stay on glhip_wsum_mfma.h.
+template <int MODE> constexpr bool wsum_uses_x32() { return MODE == WS_GAUSS_FWD; }
+
+template <int MODE, int D, typename T, bool SPARSE>
+void launch_wsum_kernel(bool x32, bool pre, dim3 grid, hipStream_t st, const WsumParams<T>& prm, const Ranges& rg, int N, int M,
+                        const SplitInfo& sp, const PackedCols& pk, const PackedQ& pq) {
+    if constexpr (wsum_uses_x32<MODE>()) {
+        if (x32 && pre) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
+        if (x32) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, false>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
+    }
+    hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+}
+
 template <int MODE, int D, typename T, class MergeOp>
 void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B,
-                 int N, int M, const Scratch& sc, hipStream_t st) {
+                 int N, int M, const Scratch& sc, bool x32, hipStream_t st) {
     static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and MFMA kernel must tile rows alike");
     static_assert(WsumShape<MODE, D>::kPart == MergeOp::kPartial, "partial formats differ");
+    constexpr int NQ = WsumShape<MODE, D>::kNQ;
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
     const long per_split = (long)B * N * MergeOp::kPartial * sizeof(float);
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
@@ -195,24 +215,44 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * MergeOp::kPartial;
     sp.xcd_grid_x = 0;
+
+    // pre-packed column records + q vectors behind the split partials (see launch_softmin_mfma_nw)
+    PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    PackedQ pq{nullptr, (long)B * M};
+    const size_t rec_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
+    auto plan_pre = [&](int ns) {
+        const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
+        if (!wsum_uses_x32<MODE>() || !x32 || !sc.ws || (double)B * N * M < 5e8) return false;
+        if (sc.bytes < part_bytes + rec_bytes + (size_t)NQ * B * M * sizeof(float)) return false;
+        pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+        pq.q = reinterpret_cast<float*>(static_cast<char*>(sc.ws) + part_bytes + rec_bytes);
+        if constexpr (wsum_uses_x32<MODE>()) {
+            if (n_ranges > 0) hipLaunchKernelGGL((wsum_pack_kernel<MODE, D, T, false>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk, pq);
+            else hipLaunchKernelGGL((wsum_pack_kernel<MODE, D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk, pq);
+        }
+        return true;
+    };
+
     if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD (workgroup_coords)
-        sp.n_splits = 8;
-        sp.xcd_grid_x = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
-        const long total = (long)sp.xcd_grid_x * B * 8;
+        const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+        const long total = (long)gx * B * 8;
         if (total < (1L << 31)) {
-            hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, false>), dim3((unsigned)total, 1, 1), dim3(kBlock), 0, st, prm, rg, N, M, sp);
-            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(sp.xcd_grid_x, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+            sp.n_splits = 8;
+            sp.xcd_grid_x = gx;
+            const bool pre = plan_pre(8);
+            launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp, pk, pq);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
         }
-        sp.xcd_grid_x = 0;
     }
+    const bool pre = plan_pre(sp.n_splits);
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, true>), dim3(n_ranges, 1, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        launch_wsum_kernel<MODE, D, T, true>(x32, pre, dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp, pk, pq);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
         const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
-        hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, false>), dim3(gx, B, sp.n_splits), dim3(kBlock), 0, st, prm, rg, N, M, sp);
+        launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp, pk, pq);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     }
@@ -220,11 +260,11 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
 
 template <int D, typename T>
 void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
-                             const Scratch& sc, hipStream_t st) {
+                             const Scratch& sc, bool x32, hipStream_t st) {
     WsumParams<T> w;
     w.x = prm.x; w.y = prm.y; w.s = prm.h; w.fwd = prm.fwd; w.g = prm.g; w.out = nullptr; w.gx = prm.gx;
     w.s2 = prm.s2; w.out_scale = prm.out_scale; w.gscale = 1.f; w.tscale = 1.f;
-    launch_wsum<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, st);
+    launch_wsum<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
 }
 
 template <int D, bool BWD, typename T>
@@ -235,7 +275,7 @@ void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_range
     else if (!BWD && mfma && kind == FWD_X32) launch_softmin_mfma<D, T, FWD_X32>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (!BWD && mfma && kind == FWD_XDL16) launch_softmin_mfma<D, T, FWD_XDL16>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (!BWD && mfma) launch_softmin_mfma<D, T, FWD_F32>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (BWD && mfma) launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (BWD && mfma) launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, kind == FWD_X32, st);
     else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
@@ -326,12 +366,12 @@ void launch_conv_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int
 
 template <int D, bool BWD, typename T>
 void launch_gauss_mfma(const ConvParams<T>& prm, float blur, const Ranges& rg, int n_ranges, int B, int N, int M,
-                       const Scratch& sc, hipStream_t st) {
+                       const Scratch& sc, bool x32, hipStream_t st) {
     WsumParams<T> w;
     w.x = prm.x; w.y = prm.y; w.s = prm.v; w.fwd = nullptr; w.g = prm.g; w.out = prm.out; w.gx = prm.gx;
     w.s2 = kLog2e / (blur * blur); w.out_scale = 1.f; w.gscale = -1.0f / (blur * blur); w.tscale = prm.t;
-    if (BWD) launch_wsum<WS_GAUSS_BWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, true>>(w, prm, rg, n_ranges, B, N, M, sc, st);
-    else launch_wsum<WS_GAUSS_FWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, false>>(w, prm, rg, n_ranges, B, N, M, sc, st);
+    if (BWD) launch_wsum<WS_GAUSS_BWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, true>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
+    else launch_wsum<WS_GAUSS_FWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, false>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
 }
 
 template <bool BWD, typename T>
@@ -351,9 +391,10 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.gscale = -1.0f / (prm.t * blur * blur);
             prm.clamp2 = 0.f;
             if ((flags & GLHIP_FLAG_NO_MFMA) == 0) {
-                if (D == 1) launch_gauss_mfma<1, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                else if (D == 2) launch_gauss_mfma<2, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                else launch_gauss_mfma<3, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                const bool x32 = (flags & GLHIP_FLAG_XDL16) == 0;
+                if (D == 1) launch_gauss_mfma<1, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
+                else if (D == 2) launch_gauss_mfma<2, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
+                else launch_gauss_mfma<3, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
             } else {
                 launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
             }
@@ -432,6 +473,14 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         }
         const size_t fwd = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 + (size_t)B * (size_t)((M + 31) / 32) * 2048;
         bytes = bytes > fwd ? bytes : fwd;
+    }
+    {
+        // weighted-sum kernels (soft-min gradient, gaussian product / gradient): split partials of up to D + 1 floats per row
+        // + packed records + up to 4 q components per column
+        const int nw = (n_ranges == 0 && M >= 65536 && ns < 8) ? 8 : ns;
+        const size_t ws = (size_t)(nw < 2 ? 0 : nw) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float) + 256 +
+                          (size_t)B * (size_t)((M + 31) / 32) * 2048 + (size_t)4 * B * M * sizeof(float);
+        bytes = bytes > ws ? bytes : ws;
     }
     return bytes;
 }

@@ -66,6 +66,8 @@ def main():
             if nm in what:
                 res["conv " + nm] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05))
                 if nm == "gauss":
+                    res["conv gauss 16x16x32"] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05, flags=16))
+                    res["conv gauss (again)"] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05))
                     res["conv gauss valu"] = timeit(lambda: hip.kernel_conv_fwd_raw(kind, xb, yb, v, 0.05, flags=2))
                     gg = torch.ones(1, N, device=dev)
                     res["conv gauss bwd (mfma)"] = timeit(lambda: hip.kernel_conv_bwd_x_raw(kind, xb, yb, v, gg, 0.05))

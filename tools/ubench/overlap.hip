@@ -113,6 +113,51 @@ __global__ void __launch_bounds__(256) kloop(float* out, int iters, float seed, 
     }
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// The inner loop of wsum_x32_kernel<WS_SOFTMIN_BWD> without LDS: chained MFMA pair, 16 exp2, 48 fmac + 16 add into 64 accumulators.
+template <int MF>
+__global__ void __launch_bounds__(256) kloop_w(float* out, int iters, float seed, unsigned long long* clk) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 ab, bb, ab2, bb2;
+    for (int i = 0; i < 8; ++i) { ab[i] = (short)(lane + i); bb[i] = (short)(lane * 3 + i); ab2[i] = (short)(lane * 5 + i); bb2[i] = (short)(lane * 7 + i); }
+    f32x16 zero, d;
+    for (int i = 0; i < 16; ++i) { zero[i] = 0.f; d[i] = seed * i; }
+    float acc[16][4];
+    for (int v = 0; v < 16; ++v) for (int c = 0; c < 4; ++c) acc[v][c] = 0.f;
+    float q0 = seed * lane, q1 = seed + lane, q2 = seed - lane;
+    for (int it = 0; it < iters; ++it) {
+        ab[0] = (short)it;
+        if (MF) {
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, zero, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab2, bb2, d, 0, 0, 0);
+        } else {
+            for (int i = 0; i < 16; ++i) d[i] = d[i] * 0.5f;   // stand-in producer (16 VALU)
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float w = __builtin_amdgcn_exp2f(d[v]);
+            acc[v][0] = __builtin_fmaf(w, q0, acc[v][0]);
+            acc[v][1] = __builtin_fmaf(w, q1, acc[v][1]);
+            acc[v][2] = __builtin_fmaf(w, q2, acc[v][2]);
+            acc[v][3] += w;
+        }
+    }
+    float s = 0.f;
+    for (int v = 0; v < 16; ++v) for (int c = 0; c < 4; ++c) s += acc[v][c];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MF> void runloop_w(int wps, int iters) {
+    const int blocks = 256 * wps;
+    hipLaunchKernelGGL(kloop_w<MF>, dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
+    (void)hipDeviceSynchronize();
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(kloop_w<MF>, dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    printf("  wsum loop (mfma pair=%d, 16 exp + 48 fmac + 16 add, 64 accumulators) : %6.1f cyc/1024 pairs/SIMD = %5.2f cyc per 64 pairs\n",
+           MF, ms * 2.4e6 / ((double)iters * wps), ms * 2.4e6 / ((double)iters * wps) / 16.0);
+}
+
 void runloop(int wps, int iters) {
     const int blocks = 256 * wps;
     hipLaunchKernelGGL(kloop, dim3(blocks), dim3(256), 0, 0, g_out, iters, 0.5f, g_clk);
@@ -153,6 +198,7 @@ int main(int argc, char** argv) {
     run<4, 0, 1, 1>(wps, iters); run<4, 0, 1, 0>(wps, iters);
     run32<0, 0>(wps, iters); run32<4, 0>(wps, iters); run32<8, 0>(wps, iters); run32<16, 0>(wps, iters);
     runloop(wps, iters);
+    runloop_w<1>(wps, iters); runloop_w<0>(wps, iters);
     run32<0, 8>(wps, iters); run32<0, 16>(wps, iters); run32<8, 8>(wps, iters); run32<16, 16>(wps, iters);
     return 0;
 }
