@@ -83,6 +83,7 @@ void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_range
 // 2 row tiles per wavefront (128 rows per workgroup): 84-126 VGPRs -> 4-5 waves/SIMD; measured equal to 4 tiles at
 // N=M=1e6 and 11-16 % faster on mid-size, batched and block-sparse problems.
 constexpr int kFwdRT = 2;
+constexpr long kFwdSlots = 256 * 3;   // resident 8-wave workgroups of the forward / gaussian x32 kernels (<= 84 VGPRs, 32 KiB LDS)
 // p = 2 forward on the matrix cores; same partial format / merge kernel as the VALU op.
 //   KIND 0: fp32 MFMA (glhip_softmin_mfma.h), 4 waves.   KIND 1: bf16x3 on 16x16x32 MFMAs (glhip_softmin_xdl.h).
 //   KIND 2: bf16x3 on 32x32x16 MFMAs, transposed blocks (glhip_softmin_x32.h) — the default.
@@ -129,11 +130,12 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        const long total = (long)gx * B * 8;
+        const int nx = xcd_splits((long)gx * B, M, kFwdSlots, fit);
+        const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
-            sp.n_splits = 8;
+            sp.n_splits = nx;
             sp.xcd_grid_x = gx;
-            if (plan_pre(8)) {
+            if (plan_pre(nx)) {
                 pack();
                 hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
             } else {
@@ -235,11 +237,12 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
 
     if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD (workgroup_coords)
         const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
-        const long total = (long)gx * B * 8;
+        const int nx = (wsum_uses_x32<MODE>() && x32) ? xcd_splits((long)gx * B, M, kFwdSlots, fit) : 8;
+        const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
-            sp.n_splits = 8;
+            sp.n_splits = nx;
             sp.xcd_grid_x = gx;
-            const bool pre = plan_pre(8);
+            const bool pre = plan_pre(nx);
             launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp, pk, pq);
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
@@ -469,7 +472,11 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         } else {
             const int ns128 = choose_splits((long)B * ((N + 127) / 128), M, 0, 1L << 30), ns256 = choose_splits((long)B * ((N + 255) / 256), M, 0, 1L << 30);
             nf = ns128 > ns256 ? ns128 : ns256;
-            if (M >= 65536 && nf < 8) nf = 8;
+            if (M >= 65536) {
+                const int x128 = xcd_splits((long)B * ((N + 127) / 128), M, kFwdSlots, 32), x256 = xcd_splits((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
+                const int nx = x128 > x256 ? x128 : x256;
+                nf = nf > nx ? nf : nx;
+            }
         }
         const size_t fwd = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 + (size_t)B * (size_t)((M + 31) / 32) * 2048;
         bytes = bytes > fwd ? bytes : fwd;
@@ -477,7 +484,11 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     {
         // weighted-sum kernels (soft-min gradient, gaussian product / gradient): split partials of up to D + 1 floats per row
         // + packed records + up to 4 q components per column
-        const int nw = (n_ranges == 0 && M >= 65536 && ns < 8) ? 8 : ns;
+        int nw = ns;
+        if (n_ranges == 0 && M >= 65536) {
+            const int nx = xcd_splits((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
+            nw = nw > nx ? nw : nx;
+        }
         const size_t ws = (size_t)(nw < 2 ? 0 : nw) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float) + 256 +
                           (size_t)B * (size_t)((M + 31) / 32) * 2048 + (size_t)4 * B * M * sizeof(float);
         bytes = bytes > ws ? bytes : ws;

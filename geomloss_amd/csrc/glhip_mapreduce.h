@@ -167,6 +167,24 @@ static inline int choose_splits(long row_blocks, int M, int n_ranges, long max_b
     return ns < 1 ? 1 : (int)ns;
 }
 
+// XCD-aware dense launches use a multiple of 8 column splits (split s runs on XCD s % 8).  All workgroups take the
+// same time, so the kernel lasts ceil(workgroups / resident slots) rounds: with 8 splits a 1e5-row problem is 4.07
+// rounds of work spread over 5 (81 %).  Take the smallest multiple of 8 (up to 32) that fills its last round to
+// >= 93 %, else the best one.  `slots` = workgroups resident on the chip (256 CUs x workgroups per CU).
+static inline int xcd_splits(long row_blocks, int M, long slots, long max_by_workspace) {
+    int best = 8;
+    double best_eff = 0.0;
+    for (int ns = 8; ns <= 32; ns += 8) {
+        if (ns > max_by_workspace || (long)M / ns < 2048) break;
+        const double w = (double)row_blocks * ns / (double)slots;
+        const double rounds = (double)((row_blocks * ns + slots - 1) / slots);
+        const double eff = w / rounds;
+        if (eff >= 0.93) return ns;
+        if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
+    }
+    return best;
+}
+
 template <class Op>
 static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges& rg, int n_ranges, int B, int N,
                                     int M, void* workspace, size_t workspace_bytes, bool allow_split,
