@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 102 /* 0.1.2 */
+#define GLHIP_VERSION 103 /* 0.1.3 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -76,9 +76,12 @@ const char* glhip_last_error(void);
  * Scratch memory.  Every reduction below accepts an optional caller-owned device buffer
  * (`workspace`, `workspace_bytes`; NULL / 0 is always valid).  With it, the columns of a row may be
  * split over several workgroups (load balance on 256 CUs) and merged by a second small kernel on the
- * same stream.  glhip_workspace_bytes returns a size that lets every entry point use its preferred
- * split for the given problem; smaller buffers are used as far as they go.  The buffer must stay
- * alive until the work queued on `stream` has run; its contents are scratch.
+ * same stream, and launches of >= 5e8 pairs of the p = 2 soft-min forward / gaussian product write every
+ * column once as 64 bytes of bf16x3 matrix-core operands (+ 4 bytes of weight) that all row blocks then
+ * copy instead of recomputing.  glhip_workspace_bytes returns a size that lets every entry point use its
+ * preferred plan for the given problem (128 MB at B = 1, N = M = 1e6, D = 3); smaller buffers are used as
+ * far as they go.  The buffer must stay alive until the work queued on `stream` has run; its contents
+ * are scratch.
  */
 size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges);
 
