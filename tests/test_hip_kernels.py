@@ -170,7 +170,42 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     assert relerr(gx.cpu().numpy()[live], refg[live]) < 5e-6
 
 
+def test_softmin_block_sparse_prepacked_path(cuda):
+    """>= 5e8 nominal pairs: the block-sparse launch copies pre-packed column records (global centre, per-column layout,
+    tiles starting at arbitrary columns) instead of packing per workgroup.  Against the oracle and the 16x16x32 kernel."""
+    rng = np.random.default_rng(5)
+    N, M, D = 23000, 24000, 3
+    x, y, h = _clouds(29, N, M, D)
+    x, y = np.sort(x, axis=0), np.sort(y, axis=0)           # loosely cluster-sorted along every axis
+    rg, tup, _, keep, ri = _random_ranges(rng, N, M, 57, 61, 0.12, cuda)
+    eps = 0.03**2
+    ref = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
+    live = np.ones(N, bool)
+    live[ri[0, 0]:ri[0, 1]] = False
+    live &= np.isfinite(ref)
+    outs = {}
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT):
+        outs[flags] = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, ranges=rg, flags=flags).cpu().numpy()
+        assert np.abs(outs[flags][live] - ref[live]).max() < 4e-7 * D + 2e-6 * np.abs(ref[live]).max(), flags
+    assert np.isposinf(outs[0][~live]).all()
+
+
 KINDS = ["gaussian", "laplacian", "energy"]
+
+
+def test_gaussian_product_many_columns(cuda):
+    """M >= 65536: XCD-aware grid with an adaptive number of column splits + pre-packed columns (32x32x16 kernel)."""
+    N, M, D = 900, 70001, 3
+    x, y, v = _clouds(77, N, M, D)
+    v = np.abs(v) / M
+    v[::7] *= -1.0                                          # signed weights are legal
+    blur = 0.07
+    ref = oracle_c.kconv("gaussian", x, y, v, blur)
+    bound = oracle_c.kconv("gaussian", x, y, np.abs(v), blur)
+    tol = 3e-6 * np.abs(ref).max() + 2.4e-7 * D / blur**2 * np.abs(bound).max()   # as in test_kernel_conv_vs_oracle
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_MFMA):
+        out = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=flags).cpu().numpy()
+        assert np.abs(out - ref).max() < tol, flags
 
 
 @pytest.mark.parametrize("kind", KINDS)
