@@ -54,6 +54,10 @@ struct Scratch {
     void* ws;
     size_t bytes;
     bool allow_split;
+    bool force_pre;     // GLHIP_FLAG_PREPACK
+    // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
+    // GLHIP_FLAG_NO_SPLIT tells us to leave alone
+    bool prepack(double pairs) const { return ws && (force_pre || (allow_split && pairs >= 5e8)); }
 };
 
 // rows per thread: 2 keeps the LDS read rate at half a ds_read_b128 per row-column step while leaving
@@ -117,7 +121,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);   // either layout fits
     auto plan_pre = [&](int ns) {
         const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
-        if (KIND != FWD_X32 || !sc.ws || (double)B * N * M < 5e8) return false;
+        if (KIND != FWD_X32 || !sc.prepack((double)B * N * M)) return false;
         if (sc.bytes < part_bytes + packed_bytes) return false;
         pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
         return true;
@@ -224,7 +228,7 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     const size_t rec_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
     auto plan_pre = [&](int ns) {
         const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
-        if (!wsum_uses_x32<MODE>() || !x32 || !sc.ws || (double)B * N * M < 5e8) return false;
+        if (!wsum_uses_x32<MODE>() || !x32 || !sc.prepack((double)B * N * M)) return false;
         if (sc.bytes < part_bytes + rec_bytes + (size_t)NQ * B * M * sizeof(float)) return false;
         pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
         pq.q = reinterpret_cast<float*>(static_cast<char*>(sc.ws) + part_bytes + rec_bytes);
@@ -510,7 +514,7 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
     rc = (in_dtype == GLHIP_F32)
              ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
              : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
@@ -530,7 +534,7 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
     StepArgs step;
     step.pot = pot;
     step.prev = prev;
@@ -554,7 +558,7 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const floa
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_bwd_x: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
     rc = (in_dtype == GLHIP_F32)
              ? softmin_typed<true, float>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
              : softmin_typed<true, bf16_t>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
@@ -573,7 +577,7 @@ int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
     rc = (in_dtype == GLHIP_F32)
              ? conv_typed<false, float>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
              : conv_typed<false, bf16_t>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, flags, st);
@@ -592,7 +596,7 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0};
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
     rc = (in_dtype == GLHIP_F32)
              ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
              : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st);

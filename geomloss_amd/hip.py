@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
 GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
-FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16 = 1, 2, 4, 8, 16
+FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK = 1, 2, 4, 8, 16, 32
 
 # every symbol include/glhip.h declares, with its ctypes signature
 _c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

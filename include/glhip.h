@@ -61,7 +61,8 @@ extern "C" {
 #define GLHIP_FLAG_NO_MFMA 2  /* p=2 softmin / gaussian: form the exponents on the VALU instead of the matrix cores */
 #define GLHIP_FLAG_NO_SPLIT 4 /* never split the columns of a row over several workgroups (ignore the workspace) */
 #define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split */
-#define GLHIP_FLAG_XDL16 16   /* p=2 softmin forward: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 */
+#define GLHIP_FLAG_XDL16 16   /* p=2 softmin forward / gaussian product: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 */
+#define GLHIP_FLAG_PREPACK 32 /* pre-pack the columns whatever the launch size (default: launches of >= 5e8 pairs); needs workspace */
 
 /* error codes */
 #define GLHIP_OK 0

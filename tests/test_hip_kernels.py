@@ -45,7 +45,8 @@ def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
     ref = oracle_c.softmin(eps, x, y, h, p)
     # every code path of the forward kernel: matrix-core / VALU exponents, with / without column splits
     for flags in (0, hip.FLAG_F32_MFMA, hip.FLAG_XDL16, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_F32_MFMA | hip.FLAG_NO_SPLIT,
-                  hip.FLAG_XDL16 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
+                  hip.FLAG_XDL16 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK,
+                  hip.FLAG_PREPACK | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags  # diam^2 <= D on the unit cube
     out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
@@ -58,15 +59,16 @@ def test_softmin_fwd_many_columns(cuda, N, M, D):
     eps = 0.05**2
     x, y, h = _clouds(N + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, 2)
-    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT):
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags
     # sorted clouds, batched, through the fused half-step entry point
     xb, yb, hb = _clouds(5, 130, M, D, B=2)
     lw = np.full((2, M), -np.log(M), np.float32)
     ref_b = np.stack([oracle_c.softmin(eps, xb[k], yb[k], lw[k] + hb[k] / eps, 2) for k in range(2)])
-    out_b = hip.sinkhorn_step(eps, _t(xb, cuda), _t(yb, cuda), _t(lw, cuda), _t(hb, cuda), None, 1.0).cpu().numpy()
-    assert np.abs(out_b - ref_b).max() < 4e-7 * D + 2e-6 * np.abs(ref_b).max()
+    for flags in (0, hip.FLAG_PREPACK):
+        out_b = hip.sinkhorn_step(eps, _t(xb, cuda), _t(yb, cuda), _t(lw, cuda), _t(hb, cuda), None, 1.0, flags=flags).cpu().numpy()
+        assert np.abs(out_b - ref_b).max() < 4e-7 * D + 2e-6 * np.abs(ref_b).max(), flags
 
 
 @pytest.mark.parametrize("N,M,D", [(300, 257, 3), (1030, 1100, 2), (200, 300, 1)])
@@ -88,15 +90,16 @@ def test_softmin_batched_and_bf16(cuda):
     B, N, M, D = 5, 300, 400, 3
     x, y, h = _clouds(11, N, M, D, B=B)
     eps = 0.05**2
-    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
-    for b in range(B):
-        assert np.abs(out[b] - oracle_c.softmin(eps, x[b], y[b], h[b], 2)).max() < 1.2e-6
-    # bf16 points: kernel widens to fp32, so parity is against the oracle on the bf16-rounded points
     xb, yb = _t(x, cuda).bfloat16(), _t(y, cuda).bfloat16()
-    out16 = hip.softmin(eps, xb, yb, _t(h, cuda)).cpu().numpy()
     xr, yr = xb.float().cpu().numpy(), yb.float().cpu().numpy()
-    for b in range(B):
-        assert np.abs(out16[b] - oracle_c.softmin(eps, xr[b], yr[b], h[b], 2)).max() < 1.2e-6
+    for flags in (0, hip.FLAG_PREPACK, hip.FLAG_XDL16):   # per-workgroup packing / pre-packed records (one centre per item)
+        out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=flags).cpu().numpy()
+        for b in range(B):
+            assert np.abs(out[b] - oracle_c.softmin(eps, x[b], y[b], h[b], 2)).max() < 1.2e-6, flags
+        # bf16 points: kernel widens to fp32, so parity is against the oracle on the bf16-rounded points
+        out16 = hip.softmin(eps, xb, yb, _t(h, cuda), flags=flags).cpu().numpy()
+        for b in range(B):
+            assert np.abs(out16[b] - oracle_c.softmin(eps, xr[b], yr[b], h[b], 2)).max() < 1.2e-6, flags
 
 
 def test_softmin_translation_robust(cuda):
@@ -157,7 +160,7 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     empty = slice(ri[0, 0], ri[0, 1])
     live = np.ones(N, bool)
     live[empty] = False
-    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT):
+    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_XDL16):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, ranges=rg, flags=flags).cpu().numpy()
         assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()   # LSE over the empty set
         assert np.abs(out[live] - ref[live]).max() < 1.2e-6 + 2e-6 * np.abs(ref[live]).max()
@@ -222,8 +225,9 @@ def test_kernel_conv_vs_oracle(cuda, kind, N, M, D):
     bound = oracle_c.kconv(kind, x, y, np.abs(v), blur) if kind == "gaussian" else None
     tol = 3e-6 * np.abs(ref).max() + (2.4e-7 * D / blur**2 * np.abs(bound).max() if kind == "gaussian" else 0)
     assert np.abs(out - ref).max() < tol
-    out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=hip.FLAG_NO_SPLIT).cpu().numpy()
-    assert np.abs(out - ref).max() < tol
+    for flags in (hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_XDL16):
+        out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=flags).cpu().numpy()
+        assert np.abs(out - ref).max() < tol, flags
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -251,7 +255,8 @@ def test_kernel_conv_block_sparse(cuda, kind):
     rg, tup, tup_t, keep, ri = _random_ranges(rng, N, M, 8, 7, 0.5, cuda)
     blur = 0.3
     g = rng.standard_normal(N).astype(np.float32)
-    for flags, tol in ((hip.FLAG_NO_MFMA, 3e-6), (0, 3e-6 if kind != "gaussian" else 1e-4)):
+    for flags, tol in ((hip.FLAG_NO_MFMA, 3e-6), (0, 3e-6 if kind != "gaussian" else 1e-4),
+                       (hip.FLAG_PREPACK, 3e-6 if kind != "gaussian" else 1e-4)):
         out = hip.kernel_conv(kind, _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg, flags=flags).cpu().numpy()
         assert relerr(out, oracle_c.kconv(kind, x, y, v, blur, ranges=tup)) < tol
         # transposed pattern (K^T @ g)
