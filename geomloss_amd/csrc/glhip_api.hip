@@ -286,6 +286,81 @@ void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_range
     else launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
 }
 
+template <typename T>
+SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* h, float* out, float eps, int p,
+                                     const float* pot, const float* prev, float alpha, float beta) {
+    const float s2 = kLog2e / eps;
+    SoftminParams<T> prm;
+    prm.x = static_cast<const T*>(x);
+    prm.y = static_cast<const T*>(y);
+    prm.h = h;
+    prm.out = out;
+    prm.fwd = nullptr;
+    prm.g = nullptr;
+    prm.gx = nullptr;
+    prm.s2 = s2;
+    prm.t = (p == 1) ? s2 : std::sqrt(0.5f * s2);
+    prm.inv_t = 1.0f / prm.t;
+    prm.out_scale = -eps * kLn2;
+    prm.clamp2 = 1e-8f * prm.t * prm.t;
+    prm.pot = pot;
+    prm.prev = prev;
+    prm.pot_scale = 1.0f / eps;
+    prm.alpha = alpha;
+    prm.beta = beta;
+    return prm;
+}
+
+// glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
+template <int D, typename T>
+void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;
+    constexpr int NW = 4, kRows = NW * 32;
+    int maxN = 0, minM = m.M[0];
+    long row_blocks = 0;
+    for (int k = 0; k < m.count; ++k) {
+        maxN = m.N[k] > maxN ? m.N[k] : maxN;
+        minM = m.M[k] < minM ? m.M[k] : minM;
+        row_blocks += (long)B * ((m.N[k] + kRows - 1) / kRows);
+    }
+    const long per_split = (long)m.count * B * maxN * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = 0;   // per problem, set in the kernels
+    sp.xcd_grid_x = 0;
+    m.ws_stride = (long)sp.n_splits * B * maxN * 2;
+    const int gx = (maxN + kRows - 1) / kRows;
+    hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
+}
+
+template <typename T>
+int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
+                const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
+                int B, int N, int M, int D, float eps, float damping, int first, const Scratch& sc, hipStream_t st) {
+    const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
+    auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
+        return make_softmin_params<T>(rows, cols, logw, out, eps, 2, first ? nullptr : pot, first ? nullptr : prev, alpha, beta);
+    };
+    SoftminMulti<T> m;
+    m.count = f_aa_out ? 4 : 2;
+    m.p[0] = one(x, y, b_log, g_ab, f_ba, f_ba_out); m.N[0] = N; m.M[0] = M;
+    m.p[1] = one(y, x, a_log, f_ba, g_ab, g_ab_out); m.N[1] = M; m.M[1] = N;
+    if (m.count == 4) {
+        m.p[2] = one(x, x, a_log, f_aa, f_aa, f_aa_out); m.N[2] = N; m.M[2] = N;
+        m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
+    } else {
+        m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+    }
+    if (D == 1) launch_iter4<1, T>(m, B, sc, st);
+    else if (D == 2) launch_iter4<2, T>(m, B, sc, st);
+    else launch_iter4<3, T>(m, B, sc, st);
+    return GLHIP_OK;
+}
+
 struct StepArgs {   // fused Sinkhorn half-step; all-default = plain soft-min
     const float* pot = nullptr;
     const float* prev = nullptr;
@@ -544,6 +619,31 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
              ? softmin_typed<false, float>(x, y, logw, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step)
              : softmin_typed<false, bf16_t>(x, y, logw, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step);
     return rc ? rc : check_launch("glhip_sinkhorn_step");
+}
+
+int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba,
+                         const float* g_ab, const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out,
+                         float* f_aa_out, float* g_bb_out, int B, int N, int M, int D, float eps, float damping, int p,
+                         int in_dtype, int first, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_sinkhorn_iter4", x, y, b_log, B, N, M, D, in_dtype, nullptr, nullptr, nullptr, 0);
+    if (rc) return rc;
+    if (p != 2 || D > 3) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_iter4: only p = 2, D <= 3 (got p = %d, D = %d)", p, D);
+    if (flags & (GLHIP_FLAG_DIRECT | GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_F32_MFMA | GLHIP_FLAG_XDL16))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_iter4: runs on the default 32x32x16 kernel only (flags = %d)", flags);
+    if (B == 0 || N == 0 || M == 0) return GLHIP_OK;
+    if (!a_log || !f_ba_out || !g_ab_out) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: NULL a_log / f_ba_out / g_ab_out");
+    if ((f_aa_out == nullptr) != (g_bb_out == nullptr)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: f_aa_out and g_bb_out go together");
+    if (!first && (!f_ba || !g_ab || (f_aa_out && (!f_aa || !g_bb))))
+        return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: NULL potential (only allowed with first != 0)");
+    if (f_ba_out == f_ba || g_ab_out == g_ab || (f_aa_out && (f_aa_out == f_aa || g_bb_out == g_bb)))
+        return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: outputs must not alias inputs (updates are simultaneous)");
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: eps must be > 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, false};
+    rc = (in_dtype == GLHIP_F32)
+             ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st)
+             : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st);
+    return rc ? rc : check_launch("glhip_sinkhorn_iter4");
 }
 
 int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const float* out, const float* grad_out,

@@ -160,21 +160,21 @@ __device__ __forceinline__ void open_interval(const Ranges& rg, int M, int q_end
     }
 }
 
-template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
-__global__ void __launch_bounds__(NW * 64)
-softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
+// The work of one workgroup: row block bx of batch item b, column split `split`.  tileX: kTileX * 4 records of LDS,
+// [column group of 32][K block][column], one 16-byte record per (column, K block).
+template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
+__device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm, const Ranges& rg, int N, int M,
+                                                     const SplitInfo& sp, const PackedCols& pk, int bx, int b, int split,
+                                                     uint4* tileX) {
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
     constexpr int kPer = (kTileX * 4) / kThreads;   // PRE: records one thread moves per tile
     static_assert((kTileX * 4) % kThreads == 0, "tile / workgroup shape");
-    __shared__ uint4 tileX[kTileX * 4];   // [column group of 32][K block][column]: one 16-byte record per (column, K block)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the loop control on the scalar unit
-    int bx, b, split;
-    workgroup_coords(sp, bx, b, split);
     const int ns = sp.n_splits;
     const int half = lane >> 5;
     const int l31 = lane & 31;
@@ -352,6 +352,56 @@ softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo 
             }
         }
     }
+}
+
+template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
+__global__ void __launch_bounds__(NW * 64)
+softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
+    __shared__ uint4 tileX[kTileX * 4];
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
+    softmin_fwd_x32_body<D, T, SPARSE, RT, NW, PRE>(prm, rg, N, M, sp, pk, bx, b, split, tileX);
+}
+
+// Up to four independent dense reductions in ONE launch — the four soft-mins of a Sinkhorn iteration
+// (glhip_sinkhorn_iter4).  grid = (max row blocks, B, n_splits * count); problem k = blockIdx.z / n_splits.
+template <typename T>
+struct SoftminMulti {
+    SoftminParams<T> p[4];
+    int N[4], M[4];
+    long ws_stride;     // floats of split workspace per problem
+    int count;
+};
+
+template <int D, typename T, int NW>
+__global__ void __launch_bounds__(NW * 64)
+softmin_fwd_x32_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
+    __shared__ uint4 tileX[kTileX * 4];
+    const int k = blockIdx.z / sp.n_splits;
+    const int split = blockIdx.z - k * sp.n_splits;
+    const int N = m.N[k], M = m.M[k];
+    if ((int)blockIdx.x * (NW * 32) >= N) return;
+    SplitInfo spk = sp;
+    spk.workspace += k * m.ws_stride;
+    spk.split_stride = (long)gridDim.y * N * 2;   // this problem's own row count
+    softmin_fwd_x32_body<D, T, false, 1, NW, false>(m.p[k], Ranges{nullptr, nullptr, nullptr}, N, M, spk, PackedCols{nullptr, 0},
+                                                    (int)blockIdx.x, (int)blockIdx.y, split, tileX);
+}
+
+template <class Op, typename T>
+__global__ void __launch_bounds__(kBlock)
+merge_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
+    constexpr int D = Op::kDim;
+    const int k = blockIdx.z;
+    const int N = m.N[k];
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * kBlock * Op::kRows;
+    if (row0 >= N) return;
+    float centre[D];
+    Op::load_centre(m.p[k], b, N, row0, centre);
+    for (int i = row0 + threadIdx.x; i < min(N, row0 + kBlock * Op::kRows); i += kBlock)
+        Op::merge_row(m.p[k], b, N, i, centre, sp.workspace + k * m.ws_stride + ((long)b * N + i) * Op::kPartial, sp.n_splits,
+                      (long)gridDim.y * N * Op::kPartial);
 }
 
 }  // namespace glhip

@@ -34,6 +34,8 @@ SIGNATURES = {
                           + _RANGES + _TAIL),
     "glhip_sinkhorn_step": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                      _c_int, _c_int] + _RANGES + _TAIL),
+    "glhip_sinkhorn_iter4": (_c_int, [_vp] * 12 + [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int, _c_int]
+                             + _TAIL),
     "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
                                      _c_int] + _RANGES + _TAIL),
     "glhip_kernel_conv_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int]
@@ -193,6 +195,30 @@ def sinkhorn_step_raw(x, y, logw, pot, prev, eps, damping, p=2, ranges=None, fla
     return out
 
 
+def sinkhorn_iter4_raw(x, y, a_log, b_log, pots, eps, damping, debias=True, flags=0):
+    """The 4 (or 2) simultaneous updates of one Sinkhorn iteration in one launch.
+
+    x (B,N,D), y (B,M,D); a_log (B,N), b_log (B,M); ``pots`` = None (initialisation) or the old potentials
+    ``(f_ba, g_ab, f_aa, g_bb)`` / ``(f_ba, g_ab)`` as (B,N) / (B,M) fp32.  Returns the new ones, same arity."""
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    first = pots is None
+    outs = [torch.empty((B, n), dtype=torch.float32, device=x.device) for n in ((N, M, N, M) if debias else (N, M))]
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    old = [None] * 4 if first else list(pots) + [None] * (4 - len(pots))
+    new = outs + [None] * (4 - len(outs))
+    with torch.cuda.device(x.device):
+        L = max(N, M)
+        nbytes = 4 * int(lib.glhip_workspace_bytes(B, L, L, D, 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        rc = lib.glhip_sinkhorn_iter4(x.data_ptr(), y.data_ptr(), a_log.data_ptr(), b_log.data_ptr(),
+                                      *[ptr(t) for t in old], *[ptr(t) for t in new], B, N, M, D, float(eps), float(damping),
+                                      2, _dtype_code(x), int(first), ptr(ws), nbytes, int(flags), _stream(x))
+    _check(rc, lib)
+    return tuple(outs)
+
+
 def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
@@ -274,6 +300,22 @@ class _Softmin(torch.autograd.Function):
         g = grad_out.reshape(out.shape).float().contiguous()
         gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
         return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None
+
+
+def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0):
+    """One whole iteration of the symmetric Sinkhorn loop on the GPU, non-differentiable (dense, p = 2, D <= 3).
+
+    x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); a_log: (N,)|(1,N)|(B,N), b_log likewise; ``pots`` None (initial potentials)
+    or the old ``(f_ba, g_ab, f_aa, g_bb)`` / ``(f_ba, g_ab)``.  Returns the new potentials, shaped like a_log / b_log."""
+    xb, yb, bl, _ = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(b_log))
+    if yb.dtype != xb.dtype:
+        yb = yb.to(xb.dtype)
+    B = xb.shape[0]
+    al = _f32(a_log).reshape(B, -1)
+    old = None if pots is None else tuple(_f32(t).reshape(B, -1) for t in pots)
+    new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & FLAG_NO_SPLIT))
+    shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)
+    return tuple(t.view(sh) for t, sh in zip(new, shapes))
 
 
 # kernel-selection knobs for A/B runs (SURVEY §5: tuning through the environment only): a GLHIP_FLAG_* bitmask

@@ -122,18 +122,37 @@ class _HipSoftmin:
         out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges)
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
+    def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):
+        """All simultaneous updates of one iteration in one launch (``glhip_sinkhorn_iter4``), or None when that
+        does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the
+        GPU on its own (those run faster as separate launches with pre-packed columns)."""
+        x, y = C_xy[0], C_xy[1]
+        if self.multiscale or self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations:
+            return None
+        B = 1 if x.dim() == 2 else x.shape[0]
+        if float(B) * x.shape[-2] * y.shape[-2] >= 5e8:
+            return None
+        return hip.sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias)
+
 
 # hipGraph mode for the launch-bound regime (small clouds): the whole autograd-free annealing loop of the online
 # backend — 4 fused launches per temperature — is captured once per (shapes, schedule) and replayed as ONE graph launch.
 # Opt-in (GEOMLOSS_HIP_GRAPH=1 or set_graph_mode(True)) and only when `diameter` is given, because the temperatures are
 # kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
+_fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
 _graphs = hip.GraphCache()
 
 
 def set_graph_mode(enabled):
     global _graph_mode
     _graph_mode = bool(enabled)
+
+
+def set_iteration_fusion(enabled):
+    """One ``glhip_sinkhorn_iter4`` launch per iteration of the online loop (default) or four ``glhip_sinkhorn_step``."""
+    global _fuse_iterations
+    _fuse_iterations = bool(enabled)
 
 
 def sinkhorn_online(

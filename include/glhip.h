@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 103 /* 0.1.3 */
+#define GLHIP_VERSION 104 /* 0.1.4 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -119,6 +119,25 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
                         const int32_t* ranges_i, const int32_t* slices_i,
                         const int32_t* redranges_j, int n_ranges,
                         void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * One whole iteration of the symmetric Sinkhorn loop in ONE launch (+ one merge launch): the four
+ * simultaneous updates of sinkhorn_divergence.py:480-493 (or the four initialisations of :461-465 when
+ * `first` != 0), each reading the OLD potentials:
+ *   f_ba' = avg(C_xy, b_log, g_ab, f_ba)    g_ab' = avg(C_yx, a_log, f_ba, g_ab)
+ *   f_aa' = avg(C_xx, a_log, f_aa, f_aa)    g_bb' = avg(C_yy, b_log, g_bb, g_bb)        (debias only)
+ * with avg(C, logw, pot, prev) = (prev + damping * softmin(eps, C, logw + pot/eps)) / 2, and
+ * damping * softmin(eps, C, logw) when `first`.  C_xy = C(x_i, y_j) etc. on the clouds x (B,N,D), y (B,M,D).
+ *   f_aa / g_bb and their outputs may be NULL together (debias = False: two reductions).
+ * Outputs must not alias inputs.  Dense, p = 2, D <= 3 only (GLHIP_EUNSUPPORTED otherwise: issue four
+ * glhip_sinkhorn_step calls instead); meant for small and mid-size problems, where four separate launches
+ * leave the chip under-filled.  Workspace: 4 * glhip_workspace_bytes(B, max(N,M), max(N,M), D, 0).
+ */
+int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const float* b_log,
+                         const float* f_ba, const float* g_ab, const float* f_aa, const float* g_bb,
+                         float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
+                         int B, int N, int M, int D, float eps, float damping, int p, int in_dtype, int first,
+                         void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Gradient of glhip_softmin_fwd with respect to x (the only differentiable argument on the

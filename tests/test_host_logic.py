@@ -60,6 +60,48 @@ def test_log_weights_and_dampening():
     assert t.grad.item() == pytest.approx(2.25)
 
 
+def test_sinkhorn_loop_with_an_iter4_hook_matches_the_plain_loop():
+    """The optional one-launch-per-iteration hook of sinkhorn_loop is semantically the four simultaneous updates."""
+    import torch
+    from geomloss_amd.sinkhorn_divergence import epsilon_schedule, log_weights, sinkhorn_loop
+    from geomloss_amd.sinkhorn_samples import softmin_tensorized
+    from geomloss_amd.utils import squared_distances
+
+    torch.manual_seed(0)
+    x, y = torch.rand(1, 40, 2), torch.rand(1, 50, 2)
+    a, b = torch.full((1, 40), 1 / 40), torch.full((1, 50), 1 / 50)
+    C = lambda u, v: squared_distances(u, v) / 2  # noqa: E731
+    costs = dict(C_xxs=C(x, x), C_yys=C(y, y), C_xys=C(x, y), C_yxs=C(y, x))
+    eps_list = epsilon_schedule(2, 1.5, 0.1, 0.6)
+
+    class Fused:
+        calls = 0
+
+        def __call__(self, eps, Cm, h):
+            return softmin_tensorized(eps, Cm, h)
+
+        def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):
+            Fused.calls += 1
+            sm = lambda Cm, lw, pot, prev: (damping * softmin_tensorized(eps, Cm, lw if pot is None else lw + pot / eps)  # noqa: E731
+                                            if prev is None else
+                                            0.5 * (prev + damping * softmin_tensorized(eps, Cm, lw + pot / eps)))
+            p4 = (None,) * 4 if pots is None else tuple(pots) + (None,) * (4 - len(pots))
+            out = [sm(costs["C_xys"], b_log, p4[1], p4[0]), sm(costs["C_yxs"], a_log, p4[0], p4[1])]
+            if debias:
+                out += [sm(costs["C_xxs"], a_log, p4[2], p4[2]), sm(costs["C_yys"], b_log, p4[3], p4[3])]
+            return tuple(out)
+
+    for debias in (True, False):
+        args = (log_weights(a), log_weights(b), costs["C_xxs"] if debias else None, costs["C_yys"] if debias else None,
+                costs["C_xys"], costs["C_yxs"], eps_list, 0.7)
+        plain = sinkhorn_loop(softmin_tensorized, *args, debias=debias)
+        Fused.calls = 0
+        fused = sinkhorn_loop(Fused(), *args, debias=debias)
+        assert Fused.calls == len(eps_list) + 1
+        for u, v in zip(plain, fused):
+            assert (u is None and v is None) or torch.allclose(u, v, atol=1e-6)
+
+
 def test_sinkhorn_loop_leaves_grad_enabled():
     x, y = torch.rand(20, 2), torch.rand(30, 2)
     with torch.no_grad():
