@@ -124,6 +124,20 @@ def sinkhorn_wallclock(dev):
     run("multiscale_1e6_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 1_000_000, True)
     run("online_1e5_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, False)
     run("gaussian_online_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, False, reps=1)
+
+    # BASELINE configs[3] on one GPU: the whole batch of 256 clouds of 4096 bf16 points (8 GPUs would take 32 each)
+    g = torch.Generator().manual_seed(2)
+    xb = torch.rand(256, 4096, 3, generator=g).to(dev).bfloat16()
+    yb = torch.rand(256, 4096, 3, generator=g).to(dev).bfloat16()
+    loss = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L = loss(xb, yb)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    out["batched_256x4096_bf16_fwd"] = {"seconds": min(ts[1:]), "first_call_seconds": ts[0], "loss_sum": float(L.sum())}
     return out
 
 
