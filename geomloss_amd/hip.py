@@ -318,6 +318,65 @@ def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0)
     return tuple(t.view(sh) for t, sh in zip(new, shapes))
 
 
+class Iter4Plan:
+    """Everything about a run of ``glhip_sinkhorn_iter4`` calls that does not change from one iteration to the next:
+    validated contiguous inputs, the scratch buffer, two sets of output buffers (an iteration reads the potentials the
+    previous one wrote, and outputs may not alias inputs).  At N ~ 1e3 the per-call Python work (checks, allocations,
+    device guard) costs more than the kernels; the plan leaves one ctypes call per iteration."""
+
+    def __init__(self, x, y, a_log, b_log, debias=True, flags=0):
+        self.lib = load_library()
+        xb, yb, bl, _ = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(b_log))
+        if yb.dtype != xb.dtype:
+            yb = yb.to(xb.dtype)
+        self.x, self.y, self.b_log = xb, yb, bl
+        B, N, D = xb.shape
+        M = yb.shape[1]
+        self.a_log = _f32(a_log).reshape(B, -1)
+        self.dims = (B, N, M, D)
+        self.debias = debias
+        self.flags = int(flags) | (ENV_FLAGS & FLAG_NO_SPLIT)
+        self.shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)[: 4 if debias else 2]
+        sizes = (N, M, N, M)[: 4 if debias else 2]
+        dev = xb.device
+        self.device = dev
+        with torch.cuda.device(dev):
+            L = max(N, M)
+            self.nbytes = 4 * int(self.lib.glhip_workspace_bytes(B, L, L, D, 0))
+            self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dev) if self.nbytes else None
+            self.sets = []
+            for _ in range(2):
+                flat = torch.empty(B * sum(sizes), dtype=torch.float32, device=dev)
+                bufs, o = [], 0
+                for n in sizes:
+                    bufs.append(flat[o:o + B * n].view(B, n))
+                    o += B * n
+                self.sets.append(bufs)
+        self.turn = 0
+        self.fixed = (xb.data_ptr(), yb.data_ptr(), self.a_log.data_ptr(), bl.data_ptr())
+        self.dtype = _dtype_code(xb)
+
+    def run(self, eps, damping, pots):
+        B, N, M, D = self.dims
+        outs = self.sets[self.turn]
+        self.turn ^= 1
+        if pots is None:
+            old = (None, None, None, None)
+        else:
+            old = tuple(t.data_ptr() if (t.dtype is torch.float32 and t.is_contiguous()) else None for t in pots)
+            if None in old:   # unusual inputs: normalise (keeps them alive until the launch is queued)
+                pots = tuple(_f32(t).reshape(B, -1) for t in pots)
+                old = tuple(t.data_ptr() for t in pots)
+            old = old + (None,) * (4 - len(old))
+        new = tuple(t.data_ptr() for t in outs) + (None,) * (4 - len(outs))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.glhip_sinkhorn_iter4(*self.fixed, *old, *new, B, N, M, D, float(eps), float(damping), 2, self.dtype,
+                                           int(pots is None), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
+                                           self.flags, stream)
+        _check(rc, self.lib)
+        return tuple(t.view(sh) for t, sh in zip(outs, self.shapes))
+
+
 # kernel-selection knobs for A/B runs (SURVEY §5: tuning through the environment only): a GLHIP_FLAG_* bitmask
 ENV_FLAGS = int(os.environ.get("GEOMLOSS_HIP_FLAGS", "0"))
 

@@ -108,6 +108,7 @@ class _HipSoftmin:
 
     def __init__(self, p, multiscale):
         self.p, self.multiscale = p, multiscale
+        self._plan = None   # (x, y, a_log, b_log, debias, hip.Iter4Plan) of the loop being run
 
     def __call__(self, eps, C, h):
         return softmin_multiscale(eps, C, h, p=self.p) if self.multiscale else softmin_online(eps, C, h, p=self.p)
@@ -132,7 +133,10 @@ class _HipSoftmin:
         B = 1 if x.dim() == 2 else x.shape[0]
         if float(B) * x.shape[-2] * y.shape[-2] >= 5e8:
             return None
-        return hip.sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias)
+        plan = self._plan
+        if plan is None or plan[0] is not x or plan[1] is not y or plan[2] is not a_log or plan[3] is not b_log or plan[4] != debias:
+            plan = self._plan = (x, y, a_log, b_log, debias, hip.Iter4Plan(x, y, a_log, b_log, debias))
+        return plan[5].run(eps, damping, pots)
 
 
 # hipGraph mode for the launch-bound regime (small clouds): the whole autograd-free annealing loop of the online
