@@ -341,9 +341,10 @@ template <typename T>
 int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
                 const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
                 int B, int N, int M, int D, float eps, float damping, int first, const Scratch& sc, hipStream_t st) {
+    // first = 0: averaged update;  1: initial potentials (no pot, no prev);  2: plain extrapolation (pot, no prev)
     const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
     auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
-        return make_softmin_params<T>(rows, cols, logw, out, eps, 2, first ? nullptr : pot, first ? nullptr : prev, alpha, beta);
+        return make_softmin_params<T>(rows, cols, logw, out, eps, 2, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
     };
     SoftminMulti<T> m;
     m.count = f_aa_out ? 4 : 2;
@@ -633,9 +634,10 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
     if (B == 0 || N == 0 || M == 0) return GLHIP_OK;
     if (!a_log || !f_ba_out || !g_ab_out) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: NULL a_log / f_ba_out / g_ab_out");
     if ((f_aa_out == nullptr) != (g_bb_out == nullptr)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: f_aa_out and g_bb_out go together");
-    if (!first && (!f_ba || !g_ab || (f_aa_out && (!f_aa || !g_bb))))
-        return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: NULL potential (only allowed with first != 0)");
-    if (f_ba_out == f_ba || g_ab_out == g_ab || (f_aa_out && (f_aa_out == f_aa || g_bb_out == g_bb)))
+    if (first < 0 || first > 2) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: first must be 0, 1 or 2 (got %d)", first);
+    if (first != 1 && (!f_ba || !g_ab || (f_aa_out && (!f_aa || !g_bb))))
+        return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: NULL potential (only allowed with first = 1)");
+    if (first != 1 && (f_ba_out == f_ba || g_ab_out == g_ab || (f_aa_out && (f_aa_out == f_aa || g_bb_out == g_bb))))
         return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: outputs must not alias inputs (updates are simultaneous)");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: eps must be > 0");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -356,10 +356,15 @@ class Iter4Plan:
         self.fixed = (xb.data_ptr(), yb.data_ptr(), self.a_log.data_ptr(), bl.data_ptr())
         self.dtype = _dtype_code(xb)
 
-    def run(self, eps, damping, pots):
+    def run(self, eps, damping, pots, last=False):
+        """pots None: initial potentials.  Otherwise the averaged update, or with ``last`` the plain, non-averaged
+        update ``damping * softmin(eps, C, logw + pot/eps)`` written to fresh tensors (the differentiable step)."""
         B, N, M, D = self.dims
-        outs = self.sets[self.turn]
-        self.turn ^= 1
+        if last:
+            outs = [torch.empty((B, n), dtype=torch.float32, device=self.device) for n in ((N, M, N, M) if self.debias else (N, M))]
+        else:
+            outs = self.sets[self.turn]
+            self.turn ^= 1
         if pots is None:
             old = (None, None, None, None)
         else:
@@ -371,10 +376,58 @@ class Iter4Plan:
         new = tuple(t.data_ptr() for t in outs) + (None,) * (4 - len(outs))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.glhip_sinkhorn_iter4(*self.fixed, *old, *new, B, N, M, D, float(eps), float(damping), 2, self.dtype,
-                                           int(pots is None), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
+                                           1 if pots is None else (2 if last else 0), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
                                            self.flags, stream)
         _check(rc, self.lib)
         return tuple(t.view(sh) for t, sh in zip(outs, self.shapes))
+
+
+class _Last4(torch.autograd.Function):
+    """The non-averaged last update of the loop (sinkhorn_divergence.py:612-623) for all potentials at once: one forward
+    launch (``glhip_sinkhorn_iter4``, first = 2); differentiable in the row cloud of each cost (x for f_ba / f_aa, y for
+    g_ab / g_bb), exactly like the four separate soft-mins it replaces."""
+
+    @staticmethod
+    def forward(ctx, x, y, plan, eps, damping, *pots):
+        outs = plan.run(eps, damping, tuple(p.detach() for p in pots), last=True)
+        ctx.plan, ctx.cfg = plan, (eps, damping, x.shape, x.dtype, y.shape, y.dtype)
+        ctx.save_for_backward(*pots, *outs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        eps, damping, xshape, xdtype, yshape, ydtype = ctx.cfg
+        B = plan.dims[0]
+        saved = ctx.saved_tensors
+        k = len(saved) // 2
+        pots, outs = saved[:k], saved[k:]
+        # (rows, columns, log-weights of the columns, potential carried by the columns) of each reduction
+        specs = [(plan.x, plan.y, plan.b_log, pots[1]), (plan.y, plan.x, plan.a_log, pots[0])]
+        if k == 4:
+            specs += [(plan.x, plan.x, plan.a_log, pots[2]), (plan.y, plan.y, plan.b_log, pots[3])]
+        gx = gy = None
+        for i, (rows, cols, logw, pot) in enumerate(specs):
+            g = grads[i]
+            if g is None or not ctx.needs_input_grad[i % 2]:
+                continue
+            h = logw + pot.reshape(B, -1) * (1.0 / eps)
+            out = outs[i].reshape(B, -1) * (1.0 / damping)            # the soft-min value itself
+            gr = softmin_bwd_x_raw(rows, cols, h, out.contiguous(), (g.reshape(B, -1).float() * damping).contiguous(), eps, 2, None,
+                                   plan.flags)
+            if i % 2 == 0:
+                gx = gr if gx is None else gx + gr
+            else:
+                gy = gr if gy is None else gy + gr
+        gx = None if gx is None else gx.reshape(xshape).to(xdtype)
+        gy = None if gy is None else gy.reshape(yshape).to(ydtype)
+        return (gx, gy, None, None, None) + (None,) * k
+
+
+def sinkhorn_last4(plan, x, y, eps, damping, pots):
+    """Differentiable last update through an :class:`Iter4Plan`; returns the new potentials shaped like the old ones."""
+    outs = _Last4.apply(x, y, plan, float(eps), float(damping), *pots)
+    return tuple(o.view(sh) for o, sh in zip(outs, plan.shapes))
 
 
 # kernel-selection knobs for A/B runs (SURVEY §5: tuning through the environment only): a GLHIP_FLAG_* bitmask

@@ -123,10 +123,10 @@ class _HipSoftmin:
         out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges)
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
-    def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):
-        """All simultaneous updates of one iteration in one launch (``glhip_sinkhorn_iter4``), or None when that
-        does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the
-        GPU on its own (those run faster as separate launches with pre-packed columns)."""
+    def _iter4_plan(self, C_xy, a_log, b_log, debias, create):
+        """The hip.Iter4Plan of the loop being run, (re)built when the inputs change; None when the one-launch-per-iteration
+        path does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the GPU
+        on its own (those run faster as separate launches with pre-packed columns)."""
         x, y = C_xy[0], C_xy[1]
         if self.multiscale or self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations:
             return None
@@ -134,9 +134,22 @@ class _HipSoftmin:
         if float(B) * x.shape[-2] * y.shape[-2] >= 5e8:
             return None
         plan = self._plan
-        if plan is None or plan[0] is not x or plan[1] is not y or plan[2] is not a_log or plan[3] is not b_log or plan[4] != debias:
-            plan = self._plan = (x, y, a_log, b_log, debias, hip.Iter4Plan(x, y, a_log, b_log, debias))
-        return plan[5].run(eps, damping, pots)
+        if plan is None or plan[0] is not x or plan[1] is not a_log or plan[2] is not b_log or plan[3] != debias:
+            if not create:
+                return None
+            plan = self._plan = (x, a_log, b_log, debias, hip.Iter4Plan(x, y, a_log, b_log, debias))
+        return plan[4]
+
+    def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):
+        """All simultaneous updates of one iteration in one launch (``glhip_sinkhorn_iter4``), or None (see _iter4_plan)."""
+        plan = self._iter4_plan(C_xy, a_log, b_log, debias, create=True)
+        return None if plan is None else plan.run(eps, damping, pots)
+
+    def last4(self, eps, C_xy, C_yx, a_log, b_log, pots, damping, debias, create=False):
+        """The differentiable, non-averaged last update of every potential as one forward launch (and one autograd node);
+        None when :meth:`iter4` did not run this loop (unless ``create``)."""
+        plan = self._iter4_plan(C_xy, a_log, b_log, debias, create=create)
+        return None if plan is None else hip.sinkhorn_last4(plan, C_xy[0], C_yx[0], eps, damping, pots)
 
 
 # hipGraph mode for the launch-bound regime (small clouds): the whole autograd-free annealing loop of the online
@@ -209,11 +222,18 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
     eps = eps_list[-1]
     damping = dampening(eps, rho)
     xd, yd = x.detach(), y.detach()
-    f_ba, g_ab = (damping * softmin(eps, (x, yd), (b_log + g_ab / eps).detach()),
-                  damping * softmin(eps, (y, xd), (a_log + f_ba / eps).detach()))
-    if debias:
-        f_aa = damping * softmin(eps, (x, xd), (a_log + f_aa / eps).detach())
-        g_bb = damping * softmin(eps, (y, yd), (b_log + g_bb / eps).detach())
+    fused = softmin.last4(eps, (x, yd), (y, xd), a_log, b_log, (f_ba, g_ab, f_aa, g_bb) if debias else (f_ba, g_ab), damping,
+                          debias, create=True)
+    if fused is not None:   # same kernels as the eager loop's last step
+        f_ba, g_ab = fused[0], fused[1]
+        if debias:
+            f_aa, g_bb = fused[2], fused[3]
+    else:
+        f_ba, g_ab = (damping * softmin(eps, (x, yd), (b_log + g_ab / eps).detach()),
+                      damping * softmin(eps, (y, xd), (a_log + f_ba / eps).detach()))
+        if debias:
+            f_aa = damping * softmin(eps, (x, xd), (a_log + f_aa / eps).detach())
+            g_bb = damping * softmin(eps, (y, yd), (b_log + g_bb / eps).detach())
     del was_enabled
     return f_aa, g_bb, g_ab, f_ba
 

@@ -126,8 +126,9 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
  * `first` != 0), each reading the OLD potentials:
  *   f_ba' = avg(C_xy, b_log, g_ab, f_ba)    g_ab' = avg(C_yx, a_log, f_ba, g_ab)
  *   f_aa' = avg(C_xx, a_log, f_aa, f_aa)    g_bb' = avg(C_yy, b_log, g_bb, g_bb)        (debias only)
- * with avg(C, logw, pot, prev) = (prev + damping * softmin(eps, C, logw + pot/eps)) / 2, and
- * damping * softmin(eps, C, logw) when `first`.  C_xy = C(x_i, y_j) etc. on the clouds x (B,N,D), y (B,M,D).
+ * with avg(C, logw, pot, prev) = (prev + damping * softmin(eps, C, logw + pot/eps)) / 2  (`first` = 0),
+ * damping * softmin(eps, C, logw)  (`first` = 1: initial potentials, :461-465), or
+ * damping * softmin(eps, C, logw + pot/eps)  (`first` = 2: the non-averaged last update, :612-623).  C_xy = C(x_i, y_j) etc. on the clouds x (B,N,D), y (B,M,D).
  *   f_aa / g_bb and their outputs may be NULL together (debias = False: two reductions).
  * Outputs must not alias inputs.  Dense, p = 2, D <= 3 only (GLHIP_EUNSUPPORTED otherwise: issue four
  * glhip_sinkhorn_step calls instead); meant for small and mid-size problems, where four separate launches
