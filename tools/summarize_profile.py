@@ -31,7 +31,7 @@ def main():
     print(open(os.path.join(out_dir, f"{tag}_kernel_trace_stats.txt")).read())
 
     counters = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc", "pmc_pipe", "pmc_util"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
@@ -59,6 +59,15 @@ def main():
             summary["l2_hit_rate"] = h / (h + m)
         if "SQ_INSTS_VALU" in c:
             summary["valu_wave_instructions_per_launch"] = c["SQ_INSTS_VALU"]["avg_per_launch"]
+        if "GRBM_GUI_ACTIVE" in c:
+            g = c["GRBM_GUI_ACTIVE"]
+            # GRBM_GUI_ACTIVE counts busy cycles of the graphics clock, summed over the 8 XCDs of the part:
+            # cycles / 8 / kernel time = effective clock under this load
+            summary["effective_clock_GHz"] = g["avg_per_launch"] / 8.0 / g["avg_kernel_ns"]
+        for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_MFMA_BF16",
+                     "VALUBusy", "MfmaUtil"):
+            if name in c:
+                summary[name + "_per_launch"] = c[name]["avg_per_launch"]
     path = os.path.join(out_dir, f"{tag}_pmc_softmin.json")
     json.dump(summary, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
