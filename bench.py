@@ -217,11 +217,13 @@ def main():
         value = world * pairs_per_launch * args.steps / elapsed
         kernel_pairs_s = pairs_per_launch / (kernel_ms * 1e-3)
         achieved = kernel_pairs_s * 4 / 1e9
-        traffic = None
+        traffic, pipes = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_softmin.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc):   # counters of this same command, collected by tools/profile_gpu.sh (separate --pmc passes)
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                pipes = {k: pj.get(k) for k in ("VALUBusy_per_launch", "MfmaUtil_per_launch", "effective_clock_GHz", "l2_hit_rate")}
             except Exception:
                 traffic = None
         compulsory = 4.0 * (n * 3 + n * 4 + n)
@@ -247,6 +249,7 @@ def main():
                           "glhip_softmin_fwd call; the x32 kernel is > 99.9 % of it)",
                 "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
                 "compulsory_bytes_per_launch": compulsory, "compulsory_GBs": compulsory / (kernel_ms * 1e-3) / 1e9,
+                "pmc": pipes,
                 "issue_model_frac": kernel_pairs_s / ISSUE_CEILING_PAIRS_PER_S,
                 "issue_model": f"{ISSUE_CYCLES_PER_64_PAIRS:.2f} SIMD cycles per 64 pairs = the exp2 + add stream alone (16 v_exp_f32 + "
                                f"16 v_add_f32 per 1024 pairs, micro-benchmarked, MFMA hidden) -> {ISSUE_CEILING_PAIRS_PER_S:.3g} pairs/s at "
