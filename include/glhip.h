@@ -80,7 +80,7 @@ const char* glhip_last_error(void);
  * same stream, and launches of >= 5e8 pairs of the p = 2 soft-min forward / gaussian product write every
  * column once as 64 bytes of bf16x3 matrix-core operands (+ 4 bytes of weight) that all row blocks then
  * copy instead of recomputing.  glhip_workspace_bytes returns a size that lets every entry point use its
- * preferred plan for the given problem (128 MB at B = 1, N = M = 1e6, D = 3); smaller buffers are used as
+ * preferred plan for the given problem (208 MB at B = 1, N = M = 1e6, D = 3); smaller buffers are used as
  * far as they go.  The buffer must stay alive until the work queued on `stream` has run; its contents
  * are scratch.
  */
