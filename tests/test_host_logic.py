@@ -162,6 +162,9 @@ def test_auto_backend_heuristic():
     assert L._choose_backend(None, None, 0, 10001, 10000, 4) == "online"
     assert SamplesLoss("sinkhorn", p=1)._choose_backend(None, None, 0, 20000, 20000, 3) == "online"
     assert SamplesLoss("gaussian")._choose_backend(None, None, 0, 20000, 20000, 3) == "online"
+    # CPU tensors keep the reference's choice for small clouds
+    import torch
+    assert L._choose_backend(None, None, 0, 2000, 2000, 3, torch.zeros(2000, 3)) == "tensorized"
 
 
 def test_multiscale_with_batch_warns_and_falls_back_to_tensorized():

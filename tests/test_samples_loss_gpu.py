@@ -148,6 +148,20 @@ def test_batched_bf16_points_cfg4_shape(cuda):
     assert relerr(L.cpu().numpy(), ref) < 1e-4
 
 
+def test_auto_backend_on_gpu_prefers_the_matrix_free_path(cuda):
+    """backend="auto": small clouds on a GPU go to the HIP online path where it applies (D <= 3, built-in cost, not fp64),
+    to the dense path otherwise; the two agree."""
+    x, y = torch.rand(300, 3, device=cuda), torch.rand(350, 3, device=cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.1)
+    assert L._choose_backend(None, None, 0, 300, 350, 3, x) == "online"
+    assert L._choose_backend(None, None, 0, 300, 350, 5, torch.rand(300, 5, device=cuda)) == "tensorized"
+    assert L._choose_backend(None, None, 0, 300, 350, 3, x.double()) == "tensorized"
+    assert SamplesLoss("sinkhorn", cost=lambda a, b: ((a[:, :, None] - b[:, None]) ** 2).sum(-1) / 2)._choose_backend(
+        None, None, 0, 300, 350, 3, x) == "tensorized"
+    auto, dense = L(x, y).item(), SamplesLoss("sinkhorn", p=2, blur=0.1, backend="tensorized")(x, y).item()
+    assert abs(auto - dense) <= 1e-5 * abs(dense)
+
+
 # ---- full-size properties (BASELINE sizes; the oracle cannot run the whole thing) -------------------
 
 @pytest.mark.parametrize("N", [100_000, 1_000_000])
