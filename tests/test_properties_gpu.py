@@ -121,3 +121,32 @@ def test_hipgraph_mode_reproduces_the_eager_loop(cuda):
             assert abs(v0 - v1) <= 1e-7 * abs(v0)
             assert (g0 - g1).abs().max().item() <= 1e-7 * g0.abs().max().item()
             assert (F0 - F1).abs().max().item() <= 1e-7
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(debias=False), dict(reach=0.5), dict(potentials=True)])
+def test_fused_iterations_reproduce_the_per_softmin_loop(cuda, kw):
+    """One launch per iteration (glhip_sinkhorn_iter4 + the fused last step) vs four glhip_sinkhorn_step launches and four
+    autograd soft-mins: same losses, potentials and gradients, batched and un-batched, fp32 and bf16 points."""
+    from geomloss_amd import sinkhorn_samples as ss
+
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=0.6, backend="online", **kw)
+    for B, dtype in ((None, torch.float32), (3, torch.bfloat16)):
+        torch.manual_seed(5)
+        shp = (lambda n: (n, 3)) if B is None else (lambda n: (B, n, 3))
+        x = torch.rand(shp(600), device=cuda).to(dtype).requires_grad_(True)
+        y = torch.rand(shp(700), device=cuda).to(dtype)
+        res = {}
+        for fused in (True, False):
+            ss.set_iteration_fusion(fused)
+            try:
+                out = L(x, y)
+                v = out[0].sum() + out[1].sum() if kw.get("potentials") else out.sum()
+                (g,) = torch.autograd.grad(v, [x])
+                res[fused] = (v.item(), g.float())
+            finally:
+                ss.set_iteration_fusion(True)
+        (v1, g1), (v0, g0) = res[True], res[False]
+        assert abs(v1 - v0) <= 2e-6 * abs(v0) + 1e-9
+        # bf16 points get bf16 gradients: the two paths may round a value to neighbouring bf16 numbers (1 ulp = 2^-8)
+        gtol = 2e-5 if dtype == torch.float32 else 2 ** -7
+        assert (g1 - g0).abs().max().item() <= gtol * g0.abs().max().item() + 1e-9
