@@ -15,20 +15,10 @@ from .samples_loss import SamplesLoss
 from . import hip
 
 
-def _out_of_scope(name, ref):
-    def raiser(*args, **kwargs):
-        raise NotImplementedError(
-            f"geomloss_amd.{name}: the grid / image path of geomloss ({ref}) is outside the scope of this package "
-            "(SURVEY.md §2 rows 6b-8); only the point-cloud `SamplesLoss` hot path is implemented."
-        )
-    raiser.__name__ = name
-    return raiser
-
-
-# kept importable, like `from geomloss import ImagesBarycenter, sinkhorn_divergence` (reference __init__.py:5-7).
-# `geomloss_amd.sinkhorn_divergence` is the solver module (the mirror of _legacy/sinkhorn_divergence.py); calling it
-# like the reference's image-OT function of the same name raises the same out-of-scope error.
-ImagesBarycenter = _out_of_scope("ImagesBarycenter", "_legacy/wasserstein_barycenter_images.py")
+# `from geomloss import ImagesBarycenter, sinkhorn_divergence` (reference __init__.py:5-7): the image / volume path.
+# `geomloss_amd.sinkhorn_divergence` is the point-cloud solver MODULE (the mirror of _legacy/sinkhorn_divergence.py); it
+# is also callable, and calling it runs the image-OT function of that name (sinkhorn_images.sinkhorn_divergence).
+from .wasserstein_barycenter_images import ImagesBarycenter  # noqa: E402
 from . import sinkhorn_divergence  # noqa: E402
 
 __all__ = ["SamplesLoss", "ImagesBarycenter", "sinkhorn_divergence", "hip"]

@@ -14,6 +14,7 @@
 #include "glhip_softmin_xdl.h"
 #include "glhip_softmin_x32.h"
 #include "glhip_wsum_x32.h"
+#include "glhip_lines.h"
 
 using namespace glhip;
 
@@ -646,6 +647,43 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
              ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st)
              : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st);
     return rc ? rc : check_launch("glhip_sinkhorn_iter4");
+}
+
+static int lines_check(const char* fn, const void* a, const void* b, long R, int N, float eps, int p) {
+    if (R < 0 || N < 0) return fail(GLHIP_EINVAL, "%s: negative size (R=%ld, N=%d)", fn, R, N);
+    if (R == 0 || N == 0) return GLHIP_OK;
+    if (!a || !b) return fail(GLHIP_EINVAL, "%s: NULL pointer", fn);
+    if (N > kLineMax) return fail(GLHIP_EUNSUPPORTED, "%s: lines of more than %d samples are not supported (N=%d)", fn, kLineMax, N);
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "%s: eps must be > 0", fn);
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "%s: p must be 1 or 2 (got %d)", fn, p);
+    return GLHIP_OK;
+}
+
+// coordinate spacing in base-2 units: pixels sit at i / N, rescaled as in utils.py:245-252
+static float lines_step(int N, float eps, int p) {
+    return p == 2 ? std::sqrt(kLog2e / (2.0f * eps)) / (float)N : kLog2e / (eps * (float)N);
+}
+
+int glhip_lse_lines_fwd(const float* h, float* out, long R, int N, float eps, int p, void* stream) {
+    int rc = lines_check("glhip_lse_lines_fwd", h, out, R, N, eps, p);
+    if (rc || R == 0 || N == 0) return rc;
+    const unsigned grid = (unsigned)(R < 262144 ? R : 262144);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p == 2) hipLaunchKernelGGL((lse_lines_fwd_kernel<2>), dim3(grid), dim3(kBlock), 0, st, h, out, R, N, lines_step(N, eps, p));
+    else hipLaunchKernelGGL((lse_lines_fwd_kernel<1>), dim3(grid), dim3(kBlock), 0, st, h, out, R, N, lines_step(N, eps, p));
+    return check_launch("glhip_lse_lines_fwd");
+}
+
+int glhip_lse_lines_bwd(const float* h, const float* lse, const float* grad_out, float* grad_h, long R, int N, float eps, int p,
+                        void* stream) {
+    int rc = lines_check("glhip_lse_lines_bwd", h, grad_h, R, N, eps, p);
+    if (rc || R == 0 || N == 0) return rc;
+    if (!lse || !grad_out) return fail(GLHIP_EINVAL, "glhip_lse_lines_bwd: NULL pointer");
+    const unsigned grid = (unsigned)(R < 262144 ? R : 262144);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p == 2) hipLaunchKernelGGL((lse_lines_bwd_kernel<2>), dim3(grid), dim3(kBlock), 0, st, h, lse, grad_out, grad_h, R, N, lines_step(N, eps, p));
+    else hipLaunchKernelGGL((lse_lines_bwd_kernel<1>), dim3(grid), dim3(kBlock), 0, st, h, lse, grad_out, grad_h, R, N, lines_step(N, eps, p));
+    return check_launch("glhip_lse_lines_bwd");
 }
 
 int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const float* out, const float* grad_out,

@@ -43,6 +43,8 @@ SIGNATURES = {
     "glhip_kernel_conv_bwd_x": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                          _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
+    "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
+    "glhip_lse_lines_bwd": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
 }
 
 _lib = None
@@ -514,6 +516,45 @@ class _SoftminDense(torch.autograd.Function):
 
 def softmin_dense(eps, C, h):
     return _SoftminDense.apply(C, h, float(eps))
+
+
+class _LseLines(torch.autograd.Function):
+    """out[..., i] = log sum_j exp(h[..., j] - c(i, j)) along the last axis of a contiguous fp32 tensor, c the (scaled)
+    squared or absolute distance between grid samples i/N and j/N (``include/glhip.h``); differentiable in h."""
+
+    @staticmethod
+    def forward(ctx, h, eps, p):
+        if not h.is_cuda:
+            raise RuntimeError("geomloss_amd: the grid soft-min runs on the HIP kernels only; move the images to a GPU.")
+        hc = h.detach().float().contiguous()
+        N = hc.shape[-1]
+        R = hc.numel() // max(N, 1)
+        out = torch.empty_like(hc)
+        lib = load_library()
+        with torch.cuda.device(hc.device):
+            rc = lib.glhip_lse_lines_fwd(hc.data_ptr(), out.data_ptr(), R, N, float(eps), int(p), _stream(hc))
+        _check(rc, lib)
+        ctx.save_for_backward(hc, out)
+        ctx.cfg = (float(eps), int(p), h.dtype)
+        return out.to(h.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        hc, out = ctx.saved_tensors
+        eps, p, dtype = ctx.cfg
+        g = grad_out.float().contiguous()
+        gh = torch.empty_like(hc)
+        N = hc.shape[-1]
+        lib = load_library()
+        with torch.cuda.device(hc.device):
+            rc = lib.glhip_lse_lines_bwd(hc.data_ptr(), out.data_ptr(), g.data_ptr(), gh.data_ptr(), hc.numel() // max(N, 1), N,
+                                         eps, p, _stream(hc))
+        _check(rc, lib)
+        return gh.to(dtype), None, None
+
+
+def lse_lines(h, eps, p=2):
+    return _LseLines.apply(h, float(eps), int(p))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,6 +1,9 @@
-"""Dense helpers shared by the tensorized code paths (reference: ``_legacy/utils.py:13-61``)."""
+"""Dense helpers shared by the tensorized code paths (reference: ``_legacy/utils.py:13-61``) and the grid helpers of
+the image / volume path (``_legacy/utils.py:64-279``)."""
 
+import numpy as np
 import torch
+from torch.nn.functional import avg_pool2d, avg_pool3d, interpolate
 
 
 def scal(a, f, batch=False):
@@ -25,3 +28,63 @@ def squared_distances(x, y):
 def distances(x, y):
     """Dense |x_i - y_j|, squared distances clamped at 1e-8 before the root (``utils.py:56-61``)."""
     return torch.sqrt(torch.clamp_min(squared_distances(x, y), 1e-8))
+
+
+# ==============================================================================
+#                     measures on regular grids: images (B,K,N,N), volumes (B,K,N,N,N)
+# ==============================================================================
+
+BATCH, CHANNEL, HEIGHT, WIDTH, DEPTH = 0, 1, 2, 3, 4
+
+
+def dimension(I):
+    """2 for images (B,K,N,N), 3 for volumes (B,K,N,N,N) (``utils.py:71-73``)."""
+    return I.dim() - 2
+
+
+def _subsample(I):
+    """Mass-preserving 2x coarsening: sums over 2^D blocks (``utils.py:76-79``)."""
+    return 4 * avg_pool2d(I, 2) if dimension(I) == 2 else 8 * avg_pool3d(I, 2)
+
+
+def pyramid(I):
+    """[1x1, 2x2, ..., NxN] coarsenings of a density, coarsest first (``utils.py:87-96``)."""
+    levels = [I]
+    for _ in range(int(np.log2(I.shape[HEIGHT]))):
+        I = _subsample(I)
+        levels.append(I)
+    return levels[::-1]
+
+
+def upsample(I):
+    """2x bi- / tri-linear refinement of a dual potential (``utils.py:99-101``)."""
+    mode = "bilinear" if dimension(I) == 2 else "trilinear"
+    return interpolate(I, scale_factor=2, mode=mode, align_corners=False)
+
+
+def log_dens(α):
+    """log of a density, -10000 where it vanishes (``utils.py:104-107``)."""
+    α_log = α.log()
+    α_log[α <= 0] = -10000.0
+    return α_log
+
+
+def softmin_grid(eps, C_xy, h_y):
+    """Soft-C-transform on a grid, one separable log-sum-exp pass per axis (``utils.py:190-279``).
+
+    ``C_xy`` is the exponent p of the cost |x-y|^p / p between pixel centres i/N of the unit square / cube; ``h_y`` is
+    (B,K,N,N) or (B,K,N,N,N).  Each pass is the HIP kernel ``glhip_lse_lines_fwd`` on the lines of one axis (the axis is
+    moved to the last position and made contiguous, as the reference does for KeOps); differentiable in ``h_y``."""
+    from . import hip
+
+    D = dimension(h_y)
+    p = C_xy
+    if p not in (1, 2):
+        raise NotImplementedError()
+    if D not in (2, 3):
+        raise ValueError("softmin_grid expects (B,K,N,N) images or (B,K,N,N,N) volumes.")
+    last = h_y.dim() - 1
+    out = hip.lse_lines(h_y, eps, p)                     # lines of the last axis
+    for axis in range(last - 1, 1, -1):                  # then every other spatial axis, swapped into last position
+        out = hip.lse_lines(out.transpose(axis, last), eps, p).transpose(axis, last)
+    return -eps * out

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 104 /* 0.1.4 */
+#define GLHIP_VERSION 105 /* 0.1.5 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -139,6 +139,19 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
                          float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
                          int B, int N, int M, int D, float eps, float damping, int p, int in_dtype, int first,
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * Log-sum-exp along the lines of a regular grid — the separable soft-min of the reference's image / volume path
+ * (SURVEY §8f, N4):
+ *   out[r, i] = log sum_j exp( h[r, j] - c(i, j) ),   c(i, j) = (x_i - x_j)^2 / (2 eps)  (p = 2)  or  |x_i - x_j| / eps  (p = 1),
+ *   x_i = i / N, for R independent lines of N <= 4096 fp32 samples stored contiguously.
+ * Replaces: the KeOps `LazyTensor.logsumexp(dim=2)` inside `softmin_grid` (_legacy/utils.py:254-270), which the
+ * reference applies once per image axis (:272-283; the caller permutes the axis of interest to the last position).
+ * glhip_lse_lines_bwd is its vector-Jacobian product:  grad_h[r, j] = sum_i grad_out[r, i] exp(h[r, j] - c(i, j) - lse[r, i]).
+ */
+int glhip_lse_lines_fwd(const float* h, float* out, long R, int N, float eps, int p, void* stream);
+int glhip_lse_lines_bwd(const float* h, const float* lse, const float* grad_out, float* grad_h, long R, int N,
+                        float eps, int p, void* stream);
 
 /*
  * Gradient of glhip_softmin_fwd with respect to x (the only differentiable argument on the

@@ -439,3 +439,136 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
         f_x[perm_x], g_y[perm_y] = F, G
         out = (f_x, g_y)
     return (out, info) if return_info else out
+
+
+# --------------------------------------------------------------------------------------------------
+#  measures on regular grids  (_legacy/utils.py:64-279, sinkhorn_images.py, wasserstein_barycenter_images.py)
+# --------------------------------------------------------------------------------------------------
+
+def lse_lines(h, eps, p=2):
+    """log sum_j exp(h[..., j] - c(i, j)) along the last axis; pixels at i/N, c = (x_i-x_j)^2/(2 eps) or |x_i-x_j|/eps
+    (utils.py:242-270: x = arange(N)/N, divided by sqrt(2 eps) (p=2) or eps (p=1))."""
+    h = np.asarray(h, np.float64)
+    N = h.shape[-1]
+    x = np.arange(N, dtype=np.float64) / N
+    d = x[:, None] - x[None, :]
+    c = d * d / (2.0 * eps) if p == 2 else np.abs(d) / eps
+    return logsumexp(h[..., None, :] - c, axis=-1)
+
+
+def softmin_grid(eps, p, h):
+    """Separable soft-min of an image (B,K,N,N) or volume (B,K,N,N,N): one lse_lines pass per spatial axis (utils.py:272-284)."""
+    h = np.asarray(h, np.float64)
+    last = h.ndim - 1
+    out = lse_lines(h, eps, p)
+    for axis in range(last - 1, 1, -1):
+        out = np.swapaxes(lse_lines(np.swapaxes(out, axis, last), eps, p), axis, last)
+    return -eps * out
+
+
+def grid_subsample(I):
+    """Sum over 2^D blocks (utils.py:76-79: 4 * avg_pool2d, 8 * avg_pool3d)."""
+    for ax in range(2, I.ndim):
+        sh = list(I.shape)
+        sh[ax:ax + 1] = [sh[ax] // 2, 2]
+        I = I.reshape(sh).sum(ax + 1)
+    return I
+
+
+def grid_pyramid(I):
+    """[1x1, ..., NxN] (utils.py:87-96)."""
+    levels = [np.asarray(I, np.float64)]
+    for _ in range(int(np.log2(I.shape[2]))):
+        levels.append(grid_subsample(levels[-1]))
+    return levels[::-1]
+
+
+def grid_upsample(I):
+    """2x multilinear interpolation with torch's align_corners=False convention (utils.py:99-101): output sample o reads
+    the input at (o + 0.5)/2 - 0.5, clamped at 0, with the right neighbour clamped at the border."""
+    for ax in range(2, I.ndim):
+        n = I.shape[ax]
+        src = np.maximum((np.arange(2 * n) + 0.5) / 2.0 - 0.5, 0.0)
+        i0 = np.floor(src).astype(int)
+        i1 = np.minimum(i0 + 1, n - 1)
+        w = (src - i0).reshape([-1 if k == ax else 1 for k in range(I.ndim)])
+        I = (1.0 - w) * np.take(I, i0, axis=ax) + w * np.take(I, i1, axis=ax)
+    return I
+
+
+def log_dens(a):
+    """utils.py:104-107."""
+    a = np.asarray(a, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.log(a)
+    out[a <= 0] = -10000.0
+    return out
+
+
+def sinkhorn_images(a, b, p=2, blur=None, reach=None, scaling=0.5, debias=True, potentials=False):
+    """sinkhorn_images.py:26-202 on dense float64 arrays: pyramid, jump schedule, the shared loop, interpolation."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if blur is None:
+        blur = 1.0 / a.shape[-1]
+    a_s, b_s = grid_pyramid(a)[1:], grid_pyramid(b)[1:]
+    a_logs, b_logs = [log_dens(t) for t in a_s], [log_dens(t) for t in b_s]
+    C_s = [p] * len(a_logs)
+    diameter = 1
+    eps = blur**p
+    rho = None if reach is None else reach**p
+    eps_list = epsilon_schedule(p, diameter, blur, scaling)
+    pixel = [diameter / t.shape[-1] for t in a_s]
+    current, jumps = pixel.pop(0), []
+    for i, e in enumerate(eps_list[1:]):
+        if current**p > e:
+            jumps.append(i + 1)
+            current = pixel.pop(0)
+    assert len(jumps) == len(a_s) - 1
+    (f_aa, g_bb, g_ab, f_ba), _ = sinkhorn_loop(
+        softmin_grid, a_logs, b_logs, C_s, C_s, C_s, C_s, eps_list, rho, jumps=jumps,
+        kernel_truncation=lambda C_xy, C_yx, C_xy_f, C_yx_f, f, g, e, truncate=None, cost=None: (C_xy_f, C_yx_f),
+        extrapolate=lambda f, g, e, lam, C, b_log, C_f: grid_upsample(f), debias=debias)
+    B = a.shape[0]
+    flat = lambda t: None if t is None else t.reshape(B, -1)  # noqa: E731
+    out = sinkhorn_cost(eps, rho, flat(a), flat(b), flat(f_aa), flat(g_bb), flat(g_ab), flat(f_ba), debias=debias,
+                        potentials=potentials)
+    if potentials:
+        return out[0].reshape(a.shape), out[1].reshape(b.shape)
+    return out
+
+
+def images_barycenter(measures, weights, blur=0, p=2, scaling_N=10, extra_iterations=0):
+    """wasserstein_barycenter_images.py:36-93, forward values (``extra_iterations`` = the reference's backward_iterations,
+    which also change the returned barycenter)."""
+    a_k, w_k = np.asarray(measures, np.float64), np.asarray(weights, np.float64)
+    if blur == 0:
+        blur = 1.0 / a_k.shape[-1]
+    w = w_k[:, :, None, None]
+
+    def iteration(f_k, g_k, d_log, eps, ak_log):
+        def bar_of(g):
+            return d_log - (softmin_grid(eps, p, ak_log + g / eps) / eps * w).sum(1, keepdims=True)
+        bar_log = bar_of(g_k)
+        ft_k = softmin_grid(eps, p, ak_log + g_k / eps)
+        gt_k = softmin_grid(eps, p, bar_log + f_k / eps)
+        f_k, g_k = (f_k + ft_k) / 2, (g_k + gt_k) / 2
+        bar_log = bar_of(g_k)
+        d_log = 0.5 * (d_log + bar_log + softmin_grid(eps, p, d_log) / eps)
+        return f_k, g_k, d_log, bar_log
+
+    ak_log_s = [log_dens(t) for t in grid_pyramid(a_k)[1:]]
+    sigma = 1.0
+    eps = sigma**p
+    f_k, g_k = softmin_grid(eps, p, ak_log_s[0]), softmin_grid(eps, p, ak_log_s[0])
+    d_log = np.ones_like(ak_log_s[0]).sum(1, keepdims=True)
+    d_log = d_log - logsumexp(d_log.reshape(d_log.shape[0], 1, -1), axis=-1)[..., None, None]
+    for n, ak_log in enumerate(ak_log_s):
+        for _ in range(scaling_N):
+            eps = sigma**p
+            f_k, g_k, d_log, bar_log = iteration(f_k, g_k, d_log, eps, ak_log)
+            sigma = max(sigma * (2 ** (-1 / scaling_N)), blur)
+        if n + 1 < len(ak_log_s):
+            f_k, g_k, d_log = grid_upsample(f_k), grid_upsample(g_k), grid_upsample(d_log)
+    for _ in range(extra_iterations):
+        f_k, g_k, d_log, bar_log = iteration(f_k, g_k, d_log, eps, ak_log)
+    return np.exp(bar_log)
