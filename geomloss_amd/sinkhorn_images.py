@@ -6,8 +6,17 @@ with the separable grid soft-min (``utils.softmin_grid`` -> HIP kernel ``glhip_l
 reduction.  Cost: |x-y|^p / p between pixel centres of the unit square / cube.
 """
 
+import torch
+
+from . import hip
 from .sinkhorn_divergence import scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import log_dens, pyramid, softmin_grid, upsample
+
+# The loop below is ~500 small launches whatever the image size (the temperatures do not depend on the data: the
+# domain is the unit cube), and nothing in it is differentiable (every soft-min input is detached, as in the reference):
+# with hipGraph mode on (GEOMLOSS_HIP_GRAPH=1 / sinkhorn_samples.set_graph_mode) it is captured once per
+# (shape, parameters) and replayed as one graph launch.
+_graphs = hip.GraphCache()
 
 
 def extrapolate(f_ba, g_ab, eps, damping, C_xy, b_log, C_xy_fine):
@@ -34,26 +43,37 @@ def sinkhorn_divergence(a, b, p=2, blur=None, reach=None, axes=None, scaling=0.5
     if scaling < 0.5:
         raise ValueError(f"Scaling value of {scaling} is too small: please use a number in [0.5, 1).")
 
-    a_s, b_s = pyramid(a)[1:], pyramid(b)[1:]           # 2x2 ... NxN
-    a_logs, b_logs = [log_dens(t) for t in a_s], [log_dens(t) for t in b_s]
-    C_s = [p] * len(a_logs)                              # the "cost object" of a level is just the exponent
-
     diameter, eps, eps_list, rho = scaling_parameters(None, None, p, blur, reach, 1, scaling)
 
-    # jump to the next finer level as soon as its pixels are resolved by the current temperature (``:153-161``)
-    pixel = [diameter / t.shape[-1] for t in a_s]
-    current, jumps = pixel.pop(0), []
-    for i, e in enumerate(eps_list[1:]):
-        if current**p > e:
-            jumps.append(i + 1)
-            current = pixel.pop(0)
-    if verbose:
-        print("Temperatures: ", eps_list)
-        print("Jumps: ", jumps)
-    assert len(jumps) == len(a_s) - 1, "There's a bug in the multicale pre-processing..."
+    def solve(a, b):
+        a_s, b_s = pyramid(a)[1:], pyramid(b)[1:]           # 2x2 ... NxN
+        a_logs, b_logs = [log_dens(t) for t in a_s], [log_dens(t) for t in b_s]
+        C_s = [p] * len(a_logs)                              # the "cost object" of a level is just the exponent
 
-    f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
-        softmin_grid, a_logs, b_logs, C_s, C_s, C_s, C_s, eps_list, rho,
-        jumps=jumps, kernel_truncation=kernel_truncation, extrapolate=extrapolate, debias=debias,
-    )
+        # jump to the next finer level as soon as its pixels are resolved by the current temperature (``:153-161``)
+        pixel = [diameter / t.shape[-1] for t in a_s]
+        current, jumps = pixel.pop(0), []
+        for i, e in enumerate(eps_list[1:]):
+            if current**p > e:
+                jumps.append(i + 1)
+                current = pixel.pop(0)
+        if verbose:
+            print("Temperatures: ", eps_list)
+            print("Jumps: ", jumps)
+        assert len(jumps) == len(a_s) - 1, "There's a bug in the multicale pre-processing..."
+
+        return sinkhorn_loop(
+            softmin_grid, a_logs, b_logs, C_s, C_s, C_s, C_s, eps_list, rho,
+            jumps=jumps, kernel_truncation=kernel_truncation, extrapolate=extrapolate, debias=debias,
+        )
+
+    from .sinkhorn_samples import graph_mode
+
+    if graph_mode() and a.is_cuda and not verbose:
+        key = (tuple(a.shape), a.dtype, a.device.index, p, float(blur), reach, float(scaling), debias)
+        with torch.no_grad():
+            f_aa, g_bb, g_ab, f_ba = _graphs.run(key, solve, (a, b))
+        torch.autograd.set_grad_enabled(True)   # what sinkhorn_loop leaves behind (reference behaviour)
+    else:
+        f_aa, g_bb, g_ab, f_ba = solve(a, b)
     return sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, batch=True, debias=debias, potentials=potentials)

@@ -166,6 +166,10 @@ def set_graph_mode(enabled):
     _graph_mode = bool(enabled)
 
 
+def graph_mode():
+    return _graph_mode
+
+
 def set_iteration_fusion(enabled):
     """One ``glhip_sinkhorn_iter4`` launch per iteration of the online loop (default) or four ``glhip_sinkhorn_step``."""
     global _fuse_iterations

@@ -14,7 +14,12 @@ for shape in ((8, 1, 64, 64), (8, 1, 256, 256), (4, 1, 512, 512), (2, 1, 64, 64,
     a = torch.rand(shape, generator=g).to(dev) ** 3; b = torch.rand(shape, generator=g).to(dev) ** 3
     dims = tuple(range(2, len(shape)))
     a, b = a / a.sum(dims, keepdim=True), b / b.sum(dims, keepdim=True)
-    print("sinkhorn_divergence %-22s %8.2f ms" % (str(shape), timeit(lambda: sinkhorn_divergence(a, b))))
+    from geomloss_amd import sinkhorn_samples as ss
+    t_eager = timeit(lambda: sinkhorn_divergence(a, b))
+    ss.set_graph_mode(True)
+    t_graph = timeit(lambda: sinkhorn_divergence(a, b))
+    ss.set_graph_mode(False)
+    print("sinkhorn_divergence %-22s %8.2f ms   (hipGraph replay: %.2f ms)" % (str(shape), t_eager, t_graph))
     N = shape[-1]; h = torch.randn(shape, generator=g).to(dev)
     t = timeit(lambda: hip.lse_lines(h, (1.0 / N) ** 2, 2), reps=20)
     print("   one line pass: %.3f ms = %.2e pairs/s" % (t, h.numel() * N / (t * 1e-3)))
