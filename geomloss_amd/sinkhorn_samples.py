@@ -220,7 +220,6 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
 
     key = (tuple(x.shape), tuple(y.shape), x.dtype, x.device.index, tuple(float(e) for e in eps_list), rho,
            softmin.p, debias)
-    was_enabled = torch.is_grad_enabled()
     f_aa, g_bb, g_ab, f_ba = _graphs.run(key, annealing, (x, y, a_log, b_log))
     torch.autograd.set_grad_enabled(True)   # what sinkhorn_loop leaves behind (reference behaviour)
     eps = eps_list[-1]
@@ -238,7 +237,6 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
         if debias:
             f_aa = damping * softmin(eps, (x, xd), (a_log + f_aa / eps).detach())
             g_bb = damping * softmin(eps, (y, yd), (b_log + g_bb / eps).detach())
-    del was_enabled
     return f_aa, g_bb, g_ab, f_ba
 
 
