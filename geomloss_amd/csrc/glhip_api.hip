@@ -115,6 +115,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * 2;
     sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
 
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
@@ -135,11 +136,13 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        const int nx = xcd_splits((long)gx * B, M, kFwdSlots, fit);
+        const int nx = (KIND == FWD_X32 && sc.prepack((double)B * N * M)) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit)
+                                                                          : xcd_splits((long)gx * B, M, kFwdSlots, fit);
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
             sp.n_splits = nx;
             sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
             if (plan_pre(nx)) {
                 pack();
                 hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
@@ -222,6 +225,7 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * MergeOp::kPartial;
     sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
 
     // pre-packed column records + q vectors behind the split partials (see launch_softmin_mfma_nw)
     PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
@@ -242,11 +246,14 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
 
     if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD (workgroup_coords)
         const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
-        const int nx = (wsum_uses_x32<MODE>() && x32) ? xcd_splits((long)gx * B, M, kFwdSlots, fit) : 8;
+        const int nx = !(wsum_uses_x32<MODE>() && x32) ? 8
+                       : sc.prepack((double)B * N * M) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit)
+                                                       : xcd_splits((long)gx * B, M, kFwdSlots, fit);
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
             sp.n_splits = nx;
             sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
             const bool pre = plan_pre(nx);
             launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp, pk, pq);
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
@@ -331,6 +338,7 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;   // per problem, set in the kernels
     sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
     m.ws_stride = (long)sp.n_splits * B * maxN * 2;
     const int gx = (maxN + kRows - 1) / kRows;
     hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
@@ -554,7 +562,7 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
             const int ns128 = choose_splits((long)B * ((N + 127) / 128), M, 0, 1L << 30), ns256 = choose_splits((long)B * ((N + 255) / 256), M, 0, 1L << 30);
             nf = ns128 > ns256 ? ns128 : ns256;
             if (M >= 65536) {
-                const int x128 = xcd_splits((long)B * ((N + 127) / 128), M, kFwdSlots, 32), x256 = xcd_splits((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
+                const int x128 = xcd_splits_prepacked((long)B * ((N + 127) / 128), M, kFwdSlots, 32), x256 = xcd_splits_prepacked((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
                 const int nx = x128 > x256 ? x128 : x256;
                 nf = nf > nx ? nf : nx;
             }
@@ -567,7 +575,7 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         // + packed records + up to 4 q components per column
         int nw = ns;
         if (n_ranges == 0 && M >= 65536) {
-            const int nx = xcd_splits((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
+            const int nx = xcd_splits_prepacked((long)B * ((N + 255) / 256), M, kFwdSlots, 32);
             nw = nw > nx ? nw : nx;
         }
         const size_t ws = (size_t)(nw < 2 ? 0 : nw) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float) + 256 +

@@ -32,6 +32,7 @@ struct SplitInfo {
     float* workspace;   // [n_splits][B*N][kPartial] floats
     long split_stride;  // floats between consecutive splits = B*N*kPartial
     int xcd_grid_x;     // > 0: 1-D XCD-aware grid (see workgroup_coords); value = number of row blocks per batch item
+    int xcd_blocks;     // XCD-aware grid: row blocks x batch items (workgroups per column split)
 };
 
 // Logical (row block, batch item, column split) of this workgroup.  Plain mode: the 3-D grid.  XCD-aware mode
@@ -41,11 +42,16 @@ struct SplitInfo {
 // being re-fetched through the fabric by every row block.
 __device__ __forceinline__ void workgroup_coords(const SplitInfo& sp, int& bx, int& by, int& bz) {
     if (sp.xcd_grid_x > 0) {
+        // linear id = ((phase * blocks + block) * 8 + xcd): XCD k runs split k of every row block first, then split
+        // k + 8, ... — at any time its L2 holds one split's columns, however many splits there are
         const int lid = blockIdx.x;
-        bz = lid % sp.n_splits;
-        const int rest = lid / sp.n_splits;
-        bx = rest % sp.xcd_grid_x;
-        by = rest / sp.xcd_grid_x;
+        const int xcd = lid & 7;
+        const int t = lid >> 3;
+        const int phase = t / sp.xcd_blocks;
+        const int block = t - phase * sp.xcd_blocks;
+        bz = phase * 8 + xcd;
+        bx = block % sp.xcd_grid_x;
+        by = block / sp.xcd_grid_x;
     } else {
         bx = blockIdx.x;
         by = blockIdx.y;
@@ -185,6 +191,14 @@ static inline int xcd_splits(long row_blocks, int M, long slots, long max_by_wor
     return best;
 }
 
+// ... and when the columns are pre-packed (64 bytes each), enough splits for one split's records to stay resident in the
+// 4 MB L2 of the XCD that streams them (workgroup_coords runs one split per XCD at a time).
+static inline int xcd_splits_prepacked(long row_blocks, int M, long slots, long max_by_workspace) {
+    int ns = xcd_splits(row_blocks, M, slots, max_by_workspace);
+    while (ns + 8 <= 32 && ns + 8 <= max_by_workspace && (double)M / ns * 64.0 > 2.5e6) ns += 8;
+    return ns;
+}
+
 template <class Op>
 static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges& rg, int n_ranges, int B, int N,
                                     int M, void* workspace, size_t workspace_bytes, bool allow_split,
@@ -198,6 +212,7 @@ static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges
     sp.workspace = static_cast<float*>(workspace);
     sp.split_stride = (long)B * N * Op::kPartial;
     sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
     if (n_ranges > 0) {
         dim3 grid(n_ranges, 1, sp.n_splits);
         hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rg, N, M, sp);
