@@ -12,7 +12,10 @@ tensorized backend generated in the build container (``tests/golden/*.npz``, pro
 installed and not vendored): for that backend the oracle restates the algorithm of
 ``sinkhorn_samples.py:453-681`` with dense masked matrices, and its clustering follows the
 documented semantics of ``pykeops.torch.cluster`` — parity of the *clustering helper* with
-pykeops itself is unpinned.
+pykeops itself is unpinned.  The grid / image path (``utils.py:64-279``, ``sinkhorn_images.py``,
+``wasserstein_barycenter_images.py``) is pinned against the reference's own files, run with a
+dense stand-in for the one pykeops primitive they call (``tests/golden/make_golden_images.py``,
+``tests/test_images_cpu.py``: agreement <= 1e-15).
 """
 
 import numpy as np
