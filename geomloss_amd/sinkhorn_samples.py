@@ -37,7 +37,8 @@ cost_routines = {
 def softmin_tensorized(eps, C_xy, h_y):
     """``-eps * logsumexp_j(h_j - C_ij / eps)`` for a dense (B,N,M) cost matrix (``:32-71``)."""
     B = C_xy.shape[0]
-    if C_xy.is_cuda:
+    # the HIP row-reduction computes in fp32: double-precision matrices (and builds without the extension) stay on PyTorch
+    if C_xy.is_cuda and C_xy.dtype != torch.float64 and hip.library_available():
         return hip.softmin_dense(eps, C_xy, h_y.view(B, -1)).to(C_xy.dtype)
     return -eps * (h_y.view(B, 1, -1) - C_xy / eps).logsumexp(2).view(B, -1)
 
@@ -213,13 +214,18 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
     from .sinkhorn_divergence import dampening
 
     def annealing(xs, ys, al, bl):
+        # A fresh soft-min object per invocation: its Iter4Plan (fp32 / contiguous copies of the clouds, scratch, ping-pong
+        # potentials) is then built INSIDE the captured region, so the copies are re-made from the static inputs on every
+        # replay and every buffer lives in the graph's private pool (a plan left over from the warm-up pass would freeze the
+        # first call's converted clouds into the graph and leave the replays writing into freed memory).
+        sm = _HipSoftmin(softmin.p, multiscale=False)
         Cxx, Cyy = ((xs, xs), (ys, ys)) if debias else (None, None)
-        out = sinkhorn_loop(softmin, al, bl, Cxx, Cyy, (xs, ys), (ys, xs), eps_list, rho, debias=debias,
+        out = sinkhorn_loop(sm, al, bl, Cxx, Cyy, (xs, ys), (ys, xs), eps_list, rho, debias=debias,
                             last_extrapolation=False)
         return out
 
-    key = (tuple(x.shape), tuple(y.shape), x.dtype, x.device.index, tuple(float(e) for e in eps_list), rho,
-           softmin.p, debias)
+    key = (tuple(x.shape), tuple(y.shape), tuple(x.stride()), tuple(y.stride()), x.dtype, y.dtype, x.device.index,
+           tuple(float(e) for e in eps_list), rho, softmin.p, debias)
     f_aa, g_bb, g_ab, f_ba = _graphs.run(key, annealing, (x, y, a_log, b_log))
     torch.autograd.set_grad_enabled(True)   # what sinkhorn_loop leaves behind (reference behaviour)
     eps = eps_list[-1]
@@ -261,7 +267,7 @@ def clusterize(a, x, scale=None, labels=None):
         return [a], [x], []
     x_lab = grid_cluster(x, scale) if labels is None else labels
     ranges_x, x_c, a_c = cluster_ranges_centroids(x, x_lab, weights=a)
-    _, perm = torch.sort(x_lab.view(-1))
+    _, perm = torch.sort(x_lab.view(-1), stable=True)
     return [a_c, a[perm]], [x_c, x[perm]], [ranges_x], perm
 
 
