@@ -383,11 +383,31 @@ def _expand_mask(keep, ranges_i, ranges_j, N, M):
     return keep[li][:, lj]
 
 
+def softmin_dense_grad_x(eps, C, x, y, h, g, p=2):
+    """d/dx of sum_i g_i softmin(eps, C, h)_i for an explicit — possibly +inf-masked — cost matrix C = C(x, y):
+    g_i sum_j P_ij dC/dx(x_i, y_j) with P = softmax_j(h_j - C_ij/eps); masked pairs carry P = 0."""
+    v = h[None, :] - C / eps
+    v = v - v.max(-1, keepdims=True)
+    P = np.exp(v)
+    P /= P.sum(-1, keepdims=True)
+    diff = x[:, None, :] - y[None, :, :]
+    if p == 1:
+        n2 = (diff * diff).sum(-1, keepdims=True)
+        diff = np.where(n2 > 1e-8, diff / np.sqrt(np.where(n2 > 1e-8, n2, 1.0)), 0.0)
+    return g[:, None] * (P[..., None] * diff).sum(1)
+
+
 def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5,
-                        cluster_scale=None, debias=True, potentials=False, return_info=False):
+                        cluster_scale=None, debias=True, potentials=False, return_info=False, grad=False):
     """Two-scale Sinkhorn on dense matrices.  Cost objects are dicts {C, x, y, ranges_x, ranges_y}; a
     truncated fine object carries C = +inf outside the kept blocks, so softmin_dense ignores those pairs
-    exactly as a block-sparse reduction does."""
+    exactly as a block-sparse reduction does.
+
+    ``grad`` (balanced loss): also returns dL/dx in the caller's point order.  Autograd only sees the last,
+    non-averaged update (sinkhorn_divergence.py:612-623) — or, when the jump falls on the last iteration, the
+    extrapolation that replaces it (:533-544, :585-599) — whose first cloud is the fine x and whose second cloud
+    and dual vector are detached: dL/dx_i = a_i [d f_ba / dx_i - d f_aa / dx_i] with the (masked) plans of those
+    soft-mins; centroids and cluster weights come out of non-differentiable histogram operations."""
     N, D = x.shape
     M = y.shape[0]
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
@@ -420,7 +440,10 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
         out_yx = dict(C_yx_f, C=np.where(mask.T, C_yx_f["C"], np.inf))
         return out_xy, out_yx
 
+    extrapolations = []
+
     def extrapolate(f, g, eps_, lam, C_xy, b_log, C_xy_f):                   # :533-544
+        extrapolations.append((eps_, C_xy_f["x"], C_xy["y"], b_log + g / eps_))
         return lam * softmin_dense(eps_, cost_matrix(C_xy_f["x"], C_xy["y"], p), b_log + g / eps_)
 
     info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), cluster_scale=cluster_scale, kept_fraction=[],
@@ -430,7 +453,7 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
     C_xxs = [obj(x_c, x_c, ranges_x, ranges_x), obj(x, x, None, None)] if debias else None
     C_yys = [obj(y_c, y_c, ranges_y, ranges_y), obj(y, y, None, None)] if debias else None
 
-    pots, _ = sinkhorn_loop(softmin, [log_weights(a_c), log_weights(a)], [log_weights(b_c), log_weights(b)],
+    pots, last = sinkhorn_loop(softmin, [log_weights(a_c), log_weights(a)], [log_weights(b_c), log_weights(b)],
                             C_xxs, C_yys, C_xys, C_yxs, eps_list, rho, jumps=jumps,
                             kernel_truncation=kernel_truncation, truncate=truncate, extrapolate=extrapolate,
                             debias=debias)
@@ -441,6 +464,21 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
         f_x, g_y = np.empty_like(F), np.empty_like(G)
         f_x[perm_x], g_y[perm_y] = F, G
         out = (f_x, g_y)
+    if grad:
+        assert rho is None and not potentials, "closed-form gradient restated for the balanced loss only"
+        if "h_ba" in last:      # the usual case: last update on the (truncated) fine costs
+            gs = softmin_dense_grad_x(last["eps"], last["C_xy"]["C"], x, y, last["h_ba"], a, p)
+            if debias:
+                gs = gs - softmin_dense_grad_x(last["eps"], last["C_xx"]["C"], x, x, last["h_aa"], a, p)
+        else:                   # jump on the last iteration: the differentiable step is the extrapolation (fine x vs coarse cloud)
+            e, xf, yc, h = extrapolations[0]                      # f_ba: fine x against the coarse y
+            gs = softmin_dense_grad_x(e, cost_matrix(xf, yc, p), xf, yc, h, a, p)
+            if debias:
+                e, xf, xc, h = extrapolations[2]                  # f_aa: fine x against the coarse x
+                gs = gs - softmin_dense_grad_x(e, cost_matrix(xf, xc, p), xf, xc, h, a, p)
+        gx = np.empty_like(gs)
+        gx[perm_x] = gs
+        out = (out, gx)
     return (out, info) if return_info else out
 
 

@@ -16,13 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
-def golden_cases():
+MID_SIZE = ("sinkhorn_p2_n8000", "gaussian_n8000")   # pin oracle/oracle_torch64.py; too big for the NumPy oracle
+
+
+def golden_cases(mid=False):
+    if mid:
+        return list(MID_SIZE)
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
         if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_")):
             continue   # special cases, and the grid-path vectors of make_golden_images.py (tests/test_images_*.py)
-        out.append(name)
+        if name not in MID_SIZE:
+            out.append(name)
     return out
 
 

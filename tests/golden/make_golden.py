@@ -65,12 +65,18 @@ CASES = {
     "energy_d3": (dict(loss="energy"), 13, 0, 190, 230, 3, True),
     "gaussian_batch": (dict(loss="gaussian", blur=0.2), 14, 2, 100, 120, 3, True),
     "gaussian_d6": (dict(loss="gaussian", blur=0.3), 15, 0, 90, 100, 6, True),
+    # mid-size cases: what pins the chunked full-size oracle (oracle/oracle_torch64.py) beyond the sizes NumPy handles
+    "sinkhorn_p2_n8000": (dict(loss="sinkhorn", p=2, blur=0.05), 16, 0, 8000, 7000, 3, True),
+    "gaussian_n8000": (dict(loss="gaussian", blur=0.05), 17, 0, 8000, 7000, 3, True),
 }
 
 
 def main():
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])          # `python make_golden.py name ...` regenerates just those cases
     for name, (kw, seed, B, N, M, D, wts) in CASES.items():
+        if only and name not in only:
+            continue
         a, x, b, y = clouds(seed, B, N, M, D, wts)
         rec = dict(a=a.numpy(), x=x.numpy(), b=b.numpy(), y=y.numpy(), kwargs=repr(kw))
         for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
@@ -79,6 +85,8 @@ def main():
         # inputs are stored in float32 (what the kernels see) when that loses nothing for the f32 run
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
         print(name, "loss f64", rec["loss_f64"], "f32", rec["loss_f32"])
+    if only:
+        return
 
     # BASELINE config 1 exactly: SamplesLoss('sinkhorn', p=2, blur=.05) tensorized, N=M=2000, 2D, fp32, CPU
     torch.manual_seed(0)

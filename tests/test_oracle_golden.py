@@ -5,7 +5,11 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases, load_golden, relerr
-from oracle import oracle_c, oracle_np
+import torch
+
+from oracle import oracle_c, oracle_np, oracle_torch64
+
+CPU = torch.device("cpu")
 
 
 def _oracle_loss(rec, **extra):
@@ -95,3 +99,52 @@ def test_multiscale_oracle_reduces_to_tensorized_without_truncation_effect():
     for tr in (3, 10):
         other = oracle_np.sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, scaling=0.8, truncate=tr)
         assert abs(other - multi) / abs(multi) < 1e-4
+
+
+# ---- the chunked float64 torch oracle (full-size checks on the GPU box) is pinned here, on the CPU -------------------
+
+def _torch64_loss(rec, **extra):
+    kw = dict(rec["kwargs"])
+    name = kw.pop("loss")
+    a, x, b, y = rec["a"], rec["x"], rec["b"], rec["y"]
+    if name == "sinkhorn":
+        return oracle_torch64.sinkhorn_loss(x, y, a, b, device=CPU, **kw, **extra)
+    return oracle_torch64.kernel_loss(name, x, y, a, b, blur=kw.get("blur", 0.05), device=CPU, **extra)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if "batch" not in n and "_d5" not in n and "_d6" not in n]
+                         + golden_cases(mid=True))
+def test_torch64_losses_potentials_gradients_match_reference_f64(name):
+    """Loss, potentials and closed-form gradients of the chunked oracle vs the reference's float64 outputs — including the
+    mid-size cases (N = 8000) that the NumPy oracle is too slow for."""
+    rec = load_golden(name)
+    assert relerr(_torch64_loss(rec), rec["loss_f64"]) < 1e-8
+    F, G = _torch64_loss(rec, potentials=True)
+    assert relerr(F, rec["F_f64"]) < 1e-7 and relerr(G, rec["G_f64"]) < 1e-7
+    if "reach" not in name:
+        _, gx, ga = _torch64_loss(rec, grad=True)
+        assert relerr(gx, rec["gx_f64"]) < 1e-7 and relerr(ga, rec["ga_f64"]) < 1e-7
+
+
+@pytest.mark.parametrize("p", [2, 1])
+def test_torch64_reductions_match_numpy_oracle(p):
+    rng = np.random.default_rng(3)
+    N, M, D = 900, 1100, 3
+    x, y = rng.random((N, D)) + 5.0, rng.random((M, D)) * 0.8 + 5.1      # off-centre clouds: the expansion is centred
+    h, g, v = rng.standard_normal(M), rng.standard_normal(N), rng.random(M)
+    x[:7] = y[:7]                                                         # coincident points (clamp of utils.py:61)
+    for eps in (0.7, 0.05**p):
+        ref = oracle_np.softmin_points(eps, x, y, h, p)
+        for kw in (dict(), dict(exact=True), dict(budget=50_000)):        # expanded / explicit differences / many chunks
+            assert np.abs(oracle_torch64.softmin(eps, x, y, h, p, device=CPU, **kw) - ref).max() < 1e-11
+        rows = np.array([5, 0, 899, 17])
+        assert np.abs(oracle_torch64.softmin(eps, x, y, h, p, device=CPU, rows=rows) - ref[rows]).max() < 1e-11
+        gref = oracle_np.softmin_points_grad_x(eps, x, y, h, g, p)
+        assert np.abs(oracle_torch64.softmin_grad_x(eps, x, y, h, g, p, device=CPU, budget=70_000) - gref).max() < 1e-10
+        assert np.abs(oracle_torch64.softmin_grad_x(eps, x, y, h, g, p, device=CPU, rows=rows) - gref[rows]).max() < 1e-10
+    if p == 2:
+        for kind, blur in (("gaussian", 0.1), ("laplacian", 0.2), ("energy", 0.05)):
+            ref = oracle_c.kconv(kind, x, y, v, blur)
+            assert relerr(oracle_torch64.kconv(kind, x, y, v, blur, device=CPU, budget=60_000), ref) < 1e-12
+            gref = oracle_c.kconv_grad_x(kind, x, y, v, g, blur)
+            assert relerr(oracle_torch64.kconv_grad_x(kind, x, y, v, g, blur, device=CPU, budget=60_000), gref) < 1e-11
