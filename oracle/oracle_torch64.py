@@ -178,11 +178,12 @@ def _weights(n, w):
 
 
 def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, debias=True,
-                  potentials=False, grad=False, device=None):
+                  potentials=False, grad=False, full=False, device=None):
     """SamplesLoss("sinkhorn", backend="online")(a, x, b, y) for ONE pair of clouds (N,D), (M,D), in float64.
 
     Returns the loss, or ``(F, G)`` with ``potentials``, or ``(loss, dL/dx, dL/da)`` with ``grad`` (balanced only; closed
-    form of SURVEY Appendix A, the same as ``oracle_np.sinkhorn_loss_and_grad``)."""
+    form of SURVEY Appendix A, the same as ``oracle_np.sinkhorn_loss_and_grad``), or with ``full`` a dict of all of these
+    plus the four raw dual potentials, from ONE run of the loop."""
     device = default_device() if device is None else device
     xn, yn = np.asarray(x, np.float64), np.asarray(y, np.float64)
     a, b = _weights(xn.shape[0], a), _weights(yn.shape[0], b)
@@ -196,15 +197,18 @@ def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=Non
     pots, last = oracle_np.sinkhorn_loop(sm, [oracle_np.log_weights(a)], [oracle_np.log_weights(b)], C_xx, C_yy,
                                          [(xt, yt)], [(yt, xt)], eps_list, rho, debias=debias)
     f_aa, g_bb, g_ab, f_ba = pots
-    out = oracle_np.sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
-    if not grad:
+    out = oracle_np.sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials and not full)
+    if not grad and not full:
         return out if potentials else float(out)
-    assert reach is None and not potentials, "closed-form gradient restated for the balanced loss only"
+    assert reach is None and (full or not potentials), "closed-form gradient restated for the balanced loss only"
     gx = softmin_grad_x(eps, xt, yt, last["h_ba"], a, p=p, device=device)
     ga = f_ba.copy()
     if debias:
         gx = gx - softmin_grad_x(eps, xt, xt, last["h_aa"], a, p=p, device=device)
         ga = ga - f_aa
+    if full:
+        F, G = oracle_np.sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=True)
+        return dict(loss=float(out), gx=gx, ga=ga, F=F, G=G, f_aa=f_aa, g_bb=g_bb, g_ab=g_ab, f_ba=f_ba)
     return float(out), gx, ga
 
 

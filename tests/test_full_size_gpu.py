@@ -1,0 +1,233 @@
+"""Parity at the sizes BASELINE.json quotes (configs[1]-[4]), against the chunked float64 oracle
+(``oracle/oracle_torch64.py``: plain torch float64 on the test GPU, pinned on the CPU against the reference
+at N = 8000 — tests/test_oracle_golden.py).  Everything goes through the C-ABI.
+
+Tolerance: BASELINE.json's bar, 1e-4 relative on the loss (and on potentials / gradients in max-norm), with
+the measured margins noted next to each assertion.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from geomloss_amd import SamplesLoss, hip
+from geomloss_amd import sinkhorn_samples as ss
+from geomloss_amd.sinkhorn_divergence import log_weights
+from oracle import oracle_torch64 as o64
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform_clouds(seed, N, M, dev, shift=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, 3, generator=g)
+    y = torch.rand(M, 3, generator=g)
+    if shift:
+        y = y * 0.6 + 0.3
+    return x.to(dev), y.to(dev)
+
+
+# ---- configs[1]: online Sinkhorn, N = M = 1e5, 3D fp32 ----------------------------------------------------------------
+
+@pytest.mark.parametrize("shift", [False, True])
+def test_cfg2_online_sinkhorn_1e5_loss_potentials_gradient(cuda, shift):
+    """BASELINE configs[1] end to end.  ``shift=False`` is the config as stated (two samples of the same law: the loss,
+    2e-5, is what is left of O(1e-1) dual terms); ``shift=True`` a transport problem with an O(1e-2) loss."""
+    N = M = 100_000
+    x, y = _uniform_clouds(11, N, M, cuda, shift)
+    kw = dict(p=2, blur=0.05)
+    ref = o64.sinkhorn_loss(x, y, full=True, device=cuda, **kw)       # one float64 run of the whole loop: 44 reductions
+    ref_loss, ref_gx, ref_F, ref_G = ref["loss"], ref["gx"], ref["F"], ref["G"]
+
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss("sinkhorn", backend="online", **kw)(xg, y)
+    (gx,) = torch.autograd.grad(L, [xg])
+    F, G = SamplesLoss("sinkhorn", backend="online", potentials=True, **kw)(x, y)
+    err_L = abs(L.item() - ref_loss) / abs(ref_loss)
+    err_g = relerr(gx.cpu().numpy(), ref_gx)
+    err_F = max(np.abs(F.cpu().numpy() - ref_F).max(), np.abs(G.cpu().numpy() - ref_G).max())
+    scale_F = max(np.abs(ref_F).max(), np.abs(ref_G).max())
+    print(f"cfg2 shift={shift}: loss {L.item():.9e} oracle {ref_loss:.9e} rel {err_L:.2e}; dL/dx rel {err_g:.2e}; "
+          f"potentials abs {err_F:.2e} (scale {scale_F:.2e})")
+    assert err_L < 1e-4
+    assert err_g < 1e-4
+    # debiased potentials f_ba - f_aa are differences of raw dual values: the error is judged on the scale of those
+    assert err_F < 1e-4 * max(np.abs(ref["f_ba"]).max(), np.abs(ref["g_ab"]).max())
+
+
+# ---- configs[3]: batched Sinkhorn, N = M = 4096, bf16 points ------------------------------------------------------------
+
+def test_cfg4_batched_bf16_4096_full_size(cuda):
+    """BASELINE configs[3] at its real cloud size (B = 16 of the 256 items: what 2 of 8 ranks hold): bf16 points, fp32 dual
+    variables, explicit diameter; oracle on the bf16-rounded points."""
+    B, N = 16, 4096
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, N, 3, generator=g).to(cuda).bfloat16()
+    y = (torch.rand(B, N, 3, generator=g) * 0.7 + 0.2).to(cuda).bfloat16()
+    kw = dict(p=2, blur=0.05, diameter=1.8)
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss("sinkhorn", backend="online", **kw)(xg, y)
+    assert L.shape == (B,) and L.dtype == torch.float32
+    (gx,) = torch.autograd.grad(L.sum(), [xg])
+    worst_L = worst_g = 0.0
+    for k in range(B):
+        ref, rgx, _ = o64.sinkhorn_loss(x[k].double(), y[k].double(), grad=True, device=cuda, **kw)
+        worst_L = max(worst_L, abs(L[k].item() - ref) / abs(ref))
+        # the gradient comes back in bf16 (the dtype of x): 2^-9 relative rounding of each entry
+        worst_g = max(worst_g, float(np.abs(gx[k].float().cpu().numpy() - rgx).max() / np.abs(rgx).max()))
+    print(f"cfg4: worst loss rel {worst_L:.2e}, worst dL/dx rel (bf16 output) {worst_g:.2e}")
+    assert worst_L < 1e-4
+    assert worst_g < 2.0 ** -8
+
+
+# ---- configs[4]: gaussian MMD ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shift", [False, True])
+def test_cfg5_gaussian_mmd_1e5_loss_and_gradient(cuda, shift):
+    N = M = 100_000
+    x, y = _uniform_clouds(13, N, M, cuda, shift)
+    ref, rgx, rga = o64.kernel_loss("gaussian", x, y, blur=0.05, grad=True, device=cuda)
+    xg = x.clone().requires_grad_(True)
+    a = torch.full((N,), 1.0 / N, device=cuda, requires_grad=True)
+    b = torch.full((M,), 1.0 / M, device=cuda)
+    L = SamplesLoss("gaussian", blur=0.05, backend="online")(a, xg, b, y)
+    gx, ga = torch.autograd.grad(L, [xg, a])
+    e = (abs(L.item() - ref) / abs(ref), relerr(gx.cpu().numpy(), rgx), relerr(ga.cpu().numpy(), rga))
+    print(f"cfg5 shift={shift}: loss {L.item():.9e} oracle {ref:.9e} rel {e[0]:.2e}; dL/dx rel {e[1]:.2e}; dL/da rel {e[2]:.2e}")
+    assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4
+
+
+# ---- the gradient / weighted-sum kernels on their large-launch paths -------------------------------------------------------
+
+BWD_FLAGS = [0, hip.FLAG_XDL16, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_DIRECT]
+
+
+@pytest.mark.parametrize("N,M", [(3000, 70_001), (70_001, 66_000)])
+def test_softmin_bwd_many_columns_vs_oracle(cuda, N, M):
+    """M >= 65536 selects the XCD-aware 1-D grid with 8-32 column splits (and pre-packed records where a kernel has them)."""
+    x, y = _uniform_clouds(3, N, M, cuda, shift=True)
+    eps = 0.05**2
+    gen = torch.Generator().manual_seed(5)
+    h = (torch.randn(M, generator=gen) * 2 - math.log(M)).to(cuda)
+    g = torch.randn(N, generator=gen).to(cuda)
+    f_ref = o64.softmin(eps, x, y, h, device=cuda)
+    ref = o64.softmin_grad_x(eps, x, y, h, g, device=cuda)
+    for flags in BWD_FLAGS:
+        xt = x.clone().requires_grad_(True)
+        out = hip.softmin(eps, xt, y, h, flags=flags)
+        assert np.abs(out.detach().cpu().numpy() - f_ref).max() < 1.5e-6, flags
+        (gx,) = torch.autograd.grad(out, [xt], grad_outputs=g)
+        assert relerr(gx.cpu().numpy(), ref) < 2e-5, flags
+
+
+@pytest.mark.parametrize("N,M", [(3000, 70_001), (70_001, 66_000)])
+def test_gaussian_gradient_many_columns_vs_oracle(cuda, N, M):
+    x, y = _uniform_clouds(7, N, M, cuda, shift=True)
+    blur = 0.07
+    gen = torch.Generator().manual_seed(6)
+    v = (torch.rand(M, generator=gen) / M).to(cuda)
+    v[::7] *= -1.0
+    g = torch.randn(N, generator=gen).to(cuda)
+    ref_x = o64.kconv_grad_x("gaussian", x, y, v, g, blur, device=cuda)
+    ref_y = o64.kconv_grad_x("gaussian", y, x, g, v, blur, device=cuda)
+    ref_v = o64.kconv("gaussian", y, x, g, blur, device=cuda)
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK):
+        xt, yt, vt = (t.clone().requires_grad_(True) for t in (x, y, v))
+        out = hip.kernel_conv("gaussian", xt, yt, vt, blur, flags=flags)
+        gx, gy, gv = torch.autograd.grad(out, [xt, yt, vt], grad_outputs=g)
+        tol = 5e-6 if flags & hip.FLAG_NO_MFMA else 1e-4      # expanded exponent on the matrix cores (test_hip_kernels.py)
+        assert relerr(gx.cpu().numpy(), ref_x) < tol, flags
+        assert relerr(gy.cpu().numpy(), ref_y) < tol, flags
+        assert relerr(gv.cpu().numpy(), ref_v) < tol, flags
+
+
+def test_gradient_kernels_1e6_sampled_rows(cuda):
+    """N = M = 1e6 (the headline size): soft-min gradient, gaussian product and gaussian gradient on the code paths they take
+    there, 64 sampled rows against the float64 oracle."""
+    N = M = 1_000_000
+    x, y = _uniform_clouds(17, N, M, cuda)
+    eps, blur = 0.05**2, 0.05
+    gen = torch.Generator().manual_seed(8)
+    h = (torch.randn(M, generator=gen) * 2 - math.log(M)).to(cuda)
+    g = torch.randn(N, generator=gen).to(cuda)
+    v = (torch.rand(M, generator=gen) / M).to(cuda)
+    rows = torch.randint(0, N, (64,), generator=gen).numpy()
+    rsel = torch.from_numpy(rows).to(cuda)
+
+    xt = x.clone().requires_grad_(True)
+    out = hip.softmin(eps, xt, y, h)
+    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=g)
+    assert np.abs(out.detach()[rsel].cpu().numpy() - o64.softmin(eps, x, y, h, rows=rows, device=cuda)).max() < 1.5e-6
+    ref = o64.softmin_grad_x(eps, x, y, h, g, rows=rows, device=cuda)
+    assert relerr(gx[rsel].cpu().numpy(), ref) < 2e-5
+
+    xt = x.clone().requires_grad_(True)
+    out = hip.kernel_conv("gaussian", xt, y, v, blur)
+    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=g)
+    assert relerr(out.detach()[rsel].cpu().numpy(), o64.kconv("gaussian", x, y, v, blur, rows=rows, device=cuda)) < 1e-4
+    ref = o64.kconv_grad_x("gaussian", x, y, v, g, blur, rows=rows, device=cuda)
+    assert relerr(gx[rsel].cpu().numpy(), ref) < 1e-4
+
+
+# ---- configs[2]: the block-sparse kernels at N = M = 1e6 with the ranges kernel truncation really produces ------------------
+
+def test_block_sparse_fwd_bwd_1e6_with_real_truncation_ranges(cuda):
+    N = M = 1_000_000
+    x, y = _uniform_clouds(19, N, M, cuda)
+    a = torch.full((N,), 1.0 / N, device=cuda)
+    b = torch.full((M,), 1.0 / M, device=cuda)
+    diameter = math.sqrt(3.0)
+    scale = diameter / (math.sqrt(3) * 2000 ** (1 / 3))          # sinkhorn_samples.py:584-585
+    [a_c, a_s], [x_c, x_s], [ranges_x], _ = ss.clusterize(a, x, scale=scale)
+    [b_c, b_s], [y_c, y_s], [ranges_y], _ = ss.clusterize(b, y, scale=scale)
+    # coarse dual potentials at the temperature of the jump (blur just under the voxel size), then the reference's rule
+    eps = (0.9 * scale) ** 2
+    F, G = SamplesLoss("sinkhorn", p=2, blur=0.9 * scale, debias=False, potentials=True, backend="online")(a_c, x_c, b_c, y_c)
+    C_c = (x_c, y_c, ranges_x, ranges_y, None)
+    C_f = (x_s, y_s, None, None, None)
+    C_xy, C_yx = ss.kernel_truncation(C_c, (y_c, x_c, ranges_y, ranges_x, None), C_f, (y_s, x_s, None, None, None), F, G, eps,
+                                      truncate=5, cost=ss.cost_routines[2])
+    rg = C_xy[4]
+    kept = 0
+    ri, sl, red = (t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    widths = red[:, 1] - red[:, 0]
+    csum = np.r_[0, np.cumsum(widths)]
+    kept = float(((ri[:, 1] - ri[:, 0]) * (csum[sl] - csum[np.r_[0, sl[:-1]]])).sum()) / (float(N) * M)
+    print(f"block-sparse 1e6: {ri.shape[0]} row clusters, {red.shape[0]} column intervals, kept fraction {kept:.3f}")
+    assert 0.01 < kept < 0.9
+
+    eps_f = 0.05**2
+    gen = torch.Generator().manual_seed(9)
+    h = (log_weights(b_s) + G_fine(gen, M, cuda) / eps_f)
+    g = torch.randn(N, generator=gen).to(cuda)
+    xt = x_s.clone().requires_grad_(True)
+    out = hip.softmin(eps_f, xt, y_s, h, ranges=rg)
+    (gx,) = torch.autograd.grad(out, [xt], grad_outputs=g)
+    out_t = hip.softmin(eps_f, y_s, x_s, h, ranges=rg.t())          # transposed pattern (the C_yx reductions)
+
+    ks = torch.randint(0, ri.shape[0], (10,), generator=gen).numpy()
+    for k in ks:
+        cols = np.concatenate([np.arange(lo, hi) for lo, hi in red[(sl[k - 1] if k else 0):sl[k]]])
+        r0, r1 = ri[k]
+        rows = np.arange(r0, r1)[:: max(1, (r1 - r0) // 6)]
+        csel = torch.from_numpy(cols).to(cuda)
+        ref = o64.softmin(eps_f, x_s, y_s[csel], h[csel], rows=rows, device=cuda)
+        rsel = torch.from_numpy(rows).to(cuda)
+        assert np.abs(out.detach()[rsel].cpu().numpy() - ref).max() < 1.5e-6, k
+        refg = o64.softmin_grad_x(eps_f, x_s, y_s[csel], h[csel], g, rows=rows, device=cuda)
+        assert relerr(gx[rsel].cpu().numpy(), refg) < 2e-5, k
+    rjt, slt, redt = (t.cpu().numpy() for t in (rg.ranges_j, rg.slices_j, rg.redranges_i))
+    for k in torch.randint(0, rjt.shape[0], (6,), generator=gen).numpy():
+        cols = np.concatenate([np.arange(lo, hi) for lo, hi in redt[(slt[k - 1] if k else 0):slt[k]]])
+        rows = np.arange(rjt[k, 0], rjt[k, 1])[:4]
+        csel = torch.from_numpy(cols).to(cuda)
+        ref = o64.softmin(eps_f, y_s, x_s[csel], h[csel], rows=rows, device=cuda)
+        assert np.abs(out_t[torch.from_numpy(rows).to(cuda)].cpu().numpy() - ref).max() < 1.5e-6, k
+
+
+def G_fine(gen, M, dev):
+    """A smooth-ish dual potential of realistic size (|g| <~ diam^2 / 2) plus noise."""
+    return (0.05 * torch.randn(M, generator=gen)).to(dev)

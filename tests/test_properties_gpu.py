@@ -123,6 +123,42 @@ def test_hipgraph_mode_reproduces_the_eager_loop(cuda):
             assert (F0 - F1).abs().max().item() <= 1e-7
 
 
+def test_hipgraph_replay_with_converted_inputs(cuda):
+    """Graph mode with inputs the kernels cannot read as they are (fp16: widened to fp32; transposed storage: made
+    contiguous).  The conversions must be part of the captured work: a replay on NEW data of the same shape has to see the new
+    data, and nothing the graph touches may be freed between replays."""
+    from geomloss_amd import sinkhorn_samples as ss
+
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")
+
+    def inputs(seed, kind):
+        g = torch.Generator().manual_seed(seed)
+        x, y = torch.rand(800, 3, generator=g).to(cuda), (torch.rand(900, 3, generator=g) * 0.8 + 0.1).to(cuda)
+        if kind == "fp16":
+            return x.half(), y.half()
+        return x.t().contiguous().t(), y.t().contiguous().t()     # (N,3) views of (3,N) storage
+
+    for kind in ("fp16", "transposed"):
+        eager = []
+        for seed in (0, 1, 2):
+            x, y = inputs(seed, kind)
+            eager.append(L(x, y).item())
+        assert abs(eager[0] - eager[1]) > 1e-3 * abs(eager[0])     # the three problems really differ
+        ss.set_graph_mode(True)
+        try:
+            graphed = []
+            for seed in (0, 1, 2):                                # capture, replay, replay
+                x, y = inputs(seed, kind)
+                graphed.append(L(x, y).item())
+                torch.cuda.empty_cache()                          # would release a plan that lived outside the graph's pool
+                junk = torch.randn(1 << 20, device=cuda)          # ... and this would be handed its memory
+                del junk
+        finally:
+            ss.set_graph_mode(False)
+        for e, g_ in zip(eager, graphed):
+            assert abs(e - g_) <= 1e-6 * abs(e), (kind, eager, graphed)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(debias=False), dict(reach=0.5), dict(potentials=True)])
 def test_fused_iterations_reproduce_the_per_softmin_loop(cuda, kw):
     """One launch per iteration (glhip_sinkhorn_iter4 + the fused last step) vs four glhip_sinkhorn_step launches and four

@@ -36,7 +36,7 @@ def test_sinkhorn_matches_reference(cuda, name, backend):
     assert relerr(L.detach().cpu().numpy(), rec["loss_f64"]) < 1e-4 or rec["kwargs"]["p"] == 1
     gx, ga = torch.autograd.grad(L.sum(), [x, a])
     # dense fp32 p=1 costs carry the reference's own cancellation error (its fp32 gradient is 1e-3 off its fp64 one)
-    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < (3e-3 if ref == "f32" and rec["kwargs"]["p"] == 1 else 1e-3)
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < (3e-3 if ref == "f32" and rec["kwargs"]["p"] == 1 else 1e-4)
     assert relerr(ga.cpu().numpy(), rec["ga_f64"]) < (3e-3 if ref == "f32" and rec["kwargs"]["p"] == 1 else 1e-4)
     F, G = SamplesLoss(backend=backend, potentials=True, **rec["kwargs"])(a.detach(), x.detach(), b, y)
     assert F.shape == rec["F_f64"].shape
@@ -83,15 +83,15 @@ def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling):
     N, M = 3500, 3000
     x, y = _two_clouds(3, N, M, kind=kind)
     a, b = np.full(N, 1 / N), np.full(M, 1 / M)
-    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
-                                              scaling=scaling, truncate=5, return_info=True)
+    (ref, ref_gx), info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
+                                                        scaling=scaling, truncate=5, return_info=True, grad=True)
     assert info["jumps"][0] < len(info["eps_list"]) - 1 and 0 < info["kept_fraction"][0] < 1
     xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
     yt = torch.from_numpy(y).to(cuda)
     L = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=scaling, backend="multiscale")(xt, yt)
     assert abs(L.item() - ref) / abs(ref) < 1e-4
     (gx,) = torch.autograd.grad(L, [xt])
-    assert torch.isfinite(gx).all()
+    assert relerr(gx.cpu().numpy(), ref_gx) < 1e-4     # gradient of the two-scale algorithm itself (truncated fine plans)
     # potentials come back in the caller's point order
     Fm, Gm = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=scaling, backend="multiscale", potentials=True)(xt.detach(), yt)
     Fo, Go = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
@@ -106,13 +106,14 @@ def test_multiscale_jump_after_last_iteration_and_labels(cuda):
     x, y = x * 0.5, y * 0.5
     a, b = np.full(N, 1 / N), np.full(M, 1 / M)
     kw = dict(p=2, blur=0.05, diameter=1.0, cluster_scale=0.02)
-    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True, **kw)
+    (ref, ref_gx), info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True,
+                                                        grad=True, **kw)
     assert info["jumps"][0] == len(info["eps_list"]) - 1
     xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
     L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(xt, yt)
     assert abs(L.item() - ref) / abs(ref) < 1e-4
     (gx,) = torch.autograd.grad(L, [xt])
-    assert torch.isfinite(gx).all() and gx.abs().max() > 0
+    assert relerr(gx.cpu().numpy(), ref_gx) < 1e-4     # here the differentiable step is the coarse-to-fine extrapolation
     # user-supplied cluster labels (6-argument call form) reproduce the automatic clustering
     from geomloss_amd.cluster import grid_cluster
     lx, ly = grid_cluster(xt.detach(), 0.02), grid_cluster(yt, 0.02)
@@ -219,10 +220,15 @@ def test_multiscale_variants_match_two_scale_oracle(cuda, kw):
     a = rng.random(N) + 0.2
     b = rng.random(M) + 0.2
     a, b = a / a.sum(), b / b.sum()
-    ref, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True, **kw)
+    balanced = kw.get("reach") is None
+    out, info = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), return_info=True,
+                                              grad=balanced, **kw)
+    ref, ref_gx = out if balanced else (out, None)
     at, bt = torch.from_numpy(a).float().to(cuda), torch.from_numpy(b).float().to(cuda)
     xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
     L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(at, xt, bt, yt)
     assert abs(L.item() - ref) / abs(ref) < 1e-4, (L.item(), ref, info["jumps"], info["kept_fraction"])
     (gx,) = torch.autograd.grad(L, [xt])
     assert torch.isfinite(gx).all()
+    if balanced:   # p = 1: unit directions from fp32 differences, same bound as the kernel-level test
+        assert relerr(gx.cpu().numpy(), ref_gx) < 1e-4, relerr(gx.cpu().numpy(), ref_gx)
