@@ -46,6 +46,10 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def _host64(a):
+    return a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+
+
 def _chunks(N, M, budget):
     rows = max(1, min(N, budget // max(M, 1)))
     return [(i, min(N, i + rows)) for i in range(0, N, rows)]
@@ -174,7 +178,7 @@ def kconv_grad_x(kind, x, y, v, g, blur=0.05, device=None, rows=None, budget=_BU
 
 
 def _weights(n, w):
-    return np.full(n, 1.0 / n) if w is None else np.asarray(w, np.float64).reshape(-1)
+    return np.full(n, 1.0 / n) if w is None else _host64(w).reshape(-1)
 
 
 def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, debias=True,
@@ -185,7 +189,7 @@ def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=Non
     form of SURVEY Appendix A, the same as ``oracle_np.sinkhorn_loss_and_grad``), or with ``full`` a dict of all of these
     plus the four raw dual potentials, from ONE run of the loop."""
     device = default_device() if device is None else device
-    xn, yn = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    xn, yn = _host64(x), _host64(y)
     a, b = _weights(xn.shape[0], a), _weights(yn.shape[0], b)
     _, eps, eps_list, rho = oracle_np.scaling_parameters(xn, yn, p, blur, reach, diameter, scaling)
     xt, yt = _t(xn, device), _t(yn, device)
@@ -215,7 +219,7 @@ def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=Non
 def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, grad=False, device=None):
     """SamplesLoss(name, backend="online")(a, x, b, y) for one pair of clouds; with ``grad``: (loss, dL/dx, dL/da)."""
     device = default_device() if device is None else device
-    xn, yn = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    xn, yn = _host64(x), _host64(y)
     a, b = _weights(xn.shape[0], a), _weights(yn.shape[0], b)
     xt, yt = _t(xn, device), _t(yn, device)
     a_x = kconv(name, xt, xt, a, blur, device)
