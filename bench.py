@@ -4,21 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Metric (BASELINE.json): soft-min pairs/s at N=M=1e6, D=3, fp32 (+ Sinkhorn wall-clock, + % of the HBM
-roofline in the dense-equivalent byte model).
+Metric (BASELINE.json): soft-min pairs/s at N=M=1e6, D=3, fp32 (+ Sinkhorn wall-clock, + roofline).
+A *pair* is one evaluation of exp(h_j - C(x_i,y_j)/eps) inside one soft-min reduction.
 
-* One "step" = one ``glhip_softmin_fwd`` launch over one synthetic problem of 1e6 x 1e6 points in 3D
-  (1e12 pair evaluations), inputs already resident in HBM.  A *pair* is one evaluation of
-  exp(h_j - C(x_i,y_j)/eps) inside the soft-min.
-* N GPUs: one process per GPU; the batch of N independent problems is sharded one per rank (weak
-  scaling, no data-path collective); each step ends with the RCCL all-reduce of one scalar, the
-  batch-loss reduction of geomloss_amd.distributed.  value = pairs of all ranks / max-over-ranks time.
-* roofline: dense-equivalent model of SURVEY §8(d): 4 algorithmic bytes per pair (the fp32 cost-matrix
-  entry the reference's tensorized formulation streams per pair) / mean kernel duration measured with
-  HIP events on the launch stream, against 8 TB/s.  The kernel never materialises that matrix, so the
-  fraction can exceed 1; the compulsory-byte and VALU views are reported next to it.
-* cpu_baseline (rank 0, N=1 only): PyTorch-CPU port of the reference's tensorized Sinkhorn
-  (oracle/tensorized_torch.py) timed on the host cores on a bounded sample.
+* N = 1 (the headline): one "step" = one ``glhip_softmin_fwd`` launch over one synthetic problem of 1e6 x 1e6 points
+  in 3D (1e12 pairs), inputs resident in HBM.  Next to it, outside the timed region: the other reductions of the hot
+  path timed with HIP events (``kernels``), the end-to-end losses of the BASELINE configs (``sinkhorn_wallclock``) and
+  the CPU baseline (``cpu_baseline``).
+* N > 1: BASELINE configs[3] — the batch of B = 256 problems of 4096 x 4096 bf16 points, sharded over the ranks by
+  ``geomloss_amd.distributed.ShardedSamplesLoss`` (one process per GPU, explicit ``diameter``, no data-path
+  collective); one step = one whole batched Sinkhorn loss (44 soft-min reductions per problem, fused four to a launch)
+  + the RCCL all-reduce of the scalar loss.  Total work is fixed (``"scaling": "strong"``); value = soft-min pairs of
+  the whole batch per second, max-over-ranks time.  The N = 1 line carries the same workload on one GPU as
+  ``sharded_batch_reference`` so that the curve has its single-GPU point.
+* roofline (N = 1): the kernel is bound by VALU issue, not by HBM — per pair it needs exactly one ``v_exp_f32`` (quarter
+  rate: 8 cycles per wave64 instruction) and one ``v_add_f32`` (2 cycles) besides the MFMA that forms the exponent:
+  peak = 256 CU x 4 SIMD x 2.4 GHz x 64 pairs / 10 cycles = 1.573e13 pairs/s.  ``achieved`` = pairs per launch /
+  mean launch duration measured here with HIP events on the launch stream.  The dense-equivalent HBM figure that
+  BASELINE.json asks for (4 algorithmic bytes per pair) is kept in ``hbm_dense_equivalent``; it
+  exceeds 1 because the kernel never streams that matrix.  ``traffic`` is null: HBM counters cannot be read inside
+  this process; the rocprofv3 PMC summary of this same command is quoted under ``builder_pmc`` with its source.
+* cpu_baseline (rank 0, N = 1): PyTorch-CPU port of the reference's tensorized Sinkhorn
+  (oracle/tensorized_torch.py, pinned to the reference by tests/test_oracle_golden.py::test_torch_port_matches_reference)
+  on BASELINE configs[0] exactly (N=M=2000, 2D, fp32) and at N=M=5000 3D.
 
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
@@ -37,13 +45,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-# Issue-bound model of the default kernel (softmin_fwd_x32_kernel), from tools/ubench/overlap.hip
-# (profiles/r01_ubench_pipes.txt): the VALU stream of 1024 pairs is 16 v_exp_f32 + 16 v_add_f32 = 200 SIMD cycles at
-# the nominal 2.4 GHz with the 32x32x16 MFMA hidden beside it (12.5 cycles per 64 pairs); the kernel's whole inner
-# loop (chained MFMA pair + that stream, no LDS) measures 13.5.
-ISSUE_CYCLES_PER_64_PAIRS = 200.0 / 16
-LOOP_CYCLES_PER_64_PAIRS = 13.5
-ISSUE_CEILING_PAIRS_PER_S = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_64_PAIRS
+CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
+# VALU issue model of one pair (guide: a wave64 VALU instruction issues over 2 cycles on a SIMD-32; transcendentals
+# run at quarter rate): v_exp_f32 8 cycles + v_add_f32 2 cycles per 64 pairs.
+NOMINAL_CYCLES_PER_64_PAIRS = 10.0
+VALU_PEAK_PAIRS_PER_S = SIMDS * CLOCK_HZ * 64 / NOMINAL_CYCLES_PER_64_PAIRS
+# measured on this part (tools/ubench, profiles/r01_ubench_pipes.txt): that exp2 + add stream alone runs at 12.5
+# cycles per 64 pairs (v_exp_f32 8.2-9.7, v_add_f32 2.5-3.1), the kernel's bare inner loop (MFMA pair + stream) at 13.5
+MEASURED_STREAM_CYCLES = 12.5
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_softmin.json")
 
 
 def log(*a):
@@ -60,43 +70,109 @@ def make_problem(n, dev, seed):
     return x[None].contiguous(), y[None].contiguous(), h[None].contiguous(), eps
 
 
-def cpu_baseline(budget_s=12.0):
+def event_ms(fn, reps, warmup=1):
+    """Mean duration of ``fn()`` in ms, HIP events recorded on torch's current stream (the stream the C-ABI launches on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    b = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for k in range(reps):
+        a[k].record()
+        fn()
+        b[k].record()
+    torch.cuda.synchronize()
+    return sum(s.elapsed_time(e) for s, e in zip(a, b)) / reps
+
+
+def cpu_baseline(budget_s=10.0):
     from oracle.tensorized_torch import sinkhorn_tensorized_cpu
 
     cores = os.cpu_count() or 1
+    # BASELINE configs[0] exactly: torch.manual_seed(0); x, y = rand(2000, 2) (tests/golden/make_golden.py, cfg1)
+    torch.manual_seed(0)
+    x1, y1 = torch.rand(2000, 2)[None], torch.rand(2000, 2)[None]
     g = torch.Generator().manual_seed(0)
-    n = 5000
-    x, y = torch.rand(1, n, 3, generator=g), torch.rand(1, n, 3, generator=g)
-    cnt = {}
-    # PyTorch's CPU ops do not scale to every core of a many-socket host: pick the fastest thread count
-    # from a short sweep on a small problem, then time the sample with it.
+    x5, y5 = torch.rand(1, 5000, 3, generator=g), torch.rand(1, 5000, 3, generator=g)
+    # PyTorch's CPU ops do not scale to every core of a many-socket host: pick the fastest thread count from a sweep
     best_t, best_threads = None, 1
     for threads in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)}):
         torch.set_num_threads(threads)
-        sinkhorn_tensorized_cpu(x[:, :300], y[:, :300])   # warm the pool
+        sinkhorn_tensorized_cpu(x1[:, :300], y1[:, :300])   # warm the pool
         t0 = time.perf_counter()
-        sinkhorn_tensorized_cpu(x[:, :1500], y[:, :1500])
+        sinkhorn_tensorized_cpu(x1, y1)
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best_t, best_threads = dt, threads
     torch.set_num_threads(best_threads)
-    times = []
-    t_all = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        sinkhorn_tensorized_cpu(x, y, count=cnt)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s or len(times) >= 5:
-            break
-    t = sorted(times)[len(times) // 2]
-    pairs = cnt["softmin_calls"] * n * n
+
+    def timed(x, y, max_runs, budget):
+        cnt, times, t_all = {}, [], time.perf_counter()
+        while len(times) < max_runs and (not times or time.perf_counter() - t_all < budget):
+            t0 = time.perf_counter()
+            loss = sinkhorn_tensorized_cpu(x, y, count=cnt)
+            times.append(time.perf_counter() - t0)
+        t = sorted(times)[len(times) // 2]
+        return cnt["softmin_calls"] * x.shape[1] * y.shape[1] / t, t, len(times), cnt["softmin_calls"], float(loss)
+
+    v1, t1, n1, c1, l1 = timed(x1, y1, 9, budget_s * 0.5)
+    v5, t5, n5, c5, _ = timed(x5, y5, 3, budget_s * 0.5)
     return {
-        "value": pairs / t, "unit": "pairs/s", "cores": best_threads, "kind": "port",
-        "sample": f"PyTorch-CPU tensorized SamplesLoss('sinkhorn',p=2,blur=.05) forward, N=M={n} 3D fp32 "
-                  f"({cnt['softmin_calls']} dense soft-mins, median of {len(times)} runs, {t:.2f} s each, "
-                  f"{best_threads} torch threads = fastest of a sweep on a host with {cores} logical cores); "
-                  "tensorized cannot run at N=1e6 (4 TB per cost matrix)",
+        "value": v1, "unit": "pairs/s", "cores": best_threads, "kind": "port",
+        "sample": f"BASELINE configs[0] exactly: PyTorch-CPU tensorized SamplesLoss('sinkhorn',p=2,blur=.05) forward, N=M=2000 2D fp32, "
+                  f"seed 0 ({c1} dense soft-mins, median of {n1} runs, {t1:.3f} s each, loss {l1:.7e}; reference value 1.9925134e-04); "
+                  f"{best_threads} torch threads = fastest of a sweep on a host with {cores} logical cores. "
+                  "Port = oracle/tensorized_torch.py (the Python reference cannot travel to the GPU box)",
+        "n5000_3d": {"value": v5, "unit": "pairs/s", "seconds": t5, "runs": n5, "softmin_calls": c5},
+        "note": "tensorized cannot run at N=1e6 (4 TB per cost matrix): no CPU number exists for the headline size",
     }
+
+
+def hot_path_kernels(dev, n=1_000_000):
+    """The other reductions of the hot path at N = M = n, each timed with HIP events around the C-ABI call."""
+    from geomloss_amd import hip
+
+    x, y, h, eps = make_problem(n, dev, seed=7)
+    g = torch.randn(1, n, device=dev)
+    v = torch.rand(1, n, device=dev) / n
+    blur = 0.05
+    out = hip.softmin_fwd_raw(x, y, h, eps, 2)
+    pairs = float(n) * n
+    res = {}
+
+    def add(name, fn, reps=3):
+        ms = event_ms(fn, reps)
+        res[name] = {"ms": ms, "pairs_per_s": pairs / (ms * 1e-3)}
+        log(f"[bench] {name}: {ms:.2f} ms  {pairs / ms * 1e3:.3e} pairs/s")
+
+    add("softmin_bwd_x_p2", lambda: hip.softmin_bwd_x_raw(x, y, h, out, g, eps, 2))
+    add("gaussian_product", lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, x, y, v, blur))
+    add("gaussian_gradient", lambda: hip.kernel_conv_bwd_x_raw(hip.GAUSSIAN, x, y, v, g, blur))
+    add("softmin_fwd_p1", lambda: hip.softmin_fwd_raw(x, y, h, 0.05, 1), reps=2)
+    add("laplacian_product", lambda: hip.kernel_conv_fwd_raw(hip.LAPLACIAN, x, y, v, blur), reps=2)
+    add("energy_product", lambda: hip.kernel_conv_fwd_raw(hip.ENERGY, x, y, v, blur), reps=2)
+    return res
+
+
+def sinkhorn_pairs(n_eps, B, N, M, debias=True):
+    """Soft-min pair evaluations of one loss: (1 + n_eps + 1) rounds of the 4 (2 without debias) simultaneous reductions."""
+    per_round = (2 * N * M + N * N + M * M) if debias else 2 * N * M
+    return float(B) * (n_eps + 2) * per_round
+
+
+def cfg4_batch(dev, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 4096, 3, generator=g).to(dev).bfloat16()
+    y = torch.rand(B, 4096, 3, generator=g).to(dev).bfloat16()
+    return x, y
+
+
+CFG4 = dict(p=2, blur=0.05, diameter=1.8, scaling=0.5)
+
+
+def cfg4_pairs(B):
+    from geomloss_amd.sinkhorn_divergence import epsilon_schedule
+    return sinkhorn_pairs(len(epsilon_schedule(2, CFG4["diameter"], CFG4["blur"], CFG4["scaling"])), B, 4096, 4096)
 
 
 def sinkhorn_wallclock(dev):
@@ -119,26 +195,159 @@ def sinkhorn_wallclock(dev):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         out[name] = {"seconds": min(ts[1:]), "first_call_seconds": ts[0], "loss": float(L.detach())}
+        log(f"[bench] {name}: {min(ts[1:]):.4f} s (first call {ts[0]:.3f} s)")
 
     run("multiscale_1e6_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 1_000_000, False)
     run("multiscale_1e6_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 1_000_000, True)
     run("online_1e5_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, False)
+    run("online_1e5_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, True)
     run("gaussian_online_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, False, reps=1)
+    run("gaussian_online_1e6_fwd_bwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, True, reps=1)
+    run("gaussian_multiscale_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="multiscale"), 1_000_000, False, reps=1)
+    return out
 
-    # BASELINE configs[3] on one GPU: the whole batch of 256 clouds of 4096 bf16 points (8 GPUs would take 32 each)
-    g = torch.Generator().manual_seed(2)
-    xb = torch.rand(256, 4096, 3, generator=g).to(dev).bfloat16()
-    yb = torch.rand(256, 4096, 3, generator=g).to(dev).bfloat16()
-    loss = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")
+
+def sharded_reference(dev, B=256, reps=3):
+    """BASELINE configs[3] with the whole batch on ONE GPU: the single-GPU point of the `--gpus N` curve."""
+    from geomloss_amd import SamplesLoss
+
+    x, y = cfg4_batch(dev, B, seed=2)
+    loss = SamplesLoss("sinkhorn", backend="online", **CFG4)
     ts = []
-    for _ in range(3):
+    for _ in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        L = loss(xb, yb)
+        L = loss(x, y).sum()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    out["batched_256x4096_bf16_fwd"] = {"seconds": min(ts[1:]), "first_call_seconds": ts[0], "loss_sum": float(L.sum())}
-    return out
+    t = min(ts[1:])
+    return {"workload": f"SamplesLoss('sinkhorn', online) B={B} N=M=4096 3D bf16, diameter=1.8, forward", "seconds": t,
+            "pairs_per_s": cfg4_pairs(B) / t, "loss_sum": float(L)}
+
+
+def run_headline(args, dev):
+    from geomloss_amd import hip
+
+    n = args.points
+    x, y, h, eps = make_problem(n, dev, seed=1000)
+    for _ in range(args.warmup):
+        hip.softmin_fwd_raw(x, y, h, eps, 2)
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record()               # same stream as the launch (torch's current stream)
+        hip.softmin_fwd_raw(x, y, h, eps, 2)
+        stops[k].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(starts, stops)) / args.steps
+
+    pairs_per_launch = float(n) * n
+    value = pairs_per_launch * args.steps / elapsed
+    kernel_pairs_s = pairs_per_launch / (kernel_ms * 1e-3)
+    dense_gbs = kernel_pairs_s * 4 / 1e9
+    compulsory = 4.0 * (n * 3 + n * 4 + n)
+    builder_pmc = None
+    pmc = os.path.join(ROOT, PMC_SUMMARY)
+    if os.path.exists(pmc):
+        try:
+            builder_pmc = dict(json.load(open(pmc)), source=f"{PMC_SUMMARY}: rocprofv3 --pmc passes of this command, run by the builder "
+                                                            "(tools/profile_gpu.sh) — NOT measured in this process")
+        except Exception:
+            builder_pmc = None
+    res = {
+        "metric": "softmin pairs/s, N=M=1e6 3D fp32 (Sinkhorn wall-clock: `sinkhorn_wallclock`; roofline: `roofline`)"
+                  if n == 1_000_000 else f"softmin pairs/s (N=M={n} 3D fp32)",
+        "value": value, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"glhip_softmin_fwd dense, N=M={n}, D=3, p=2, eps=0.05^2, uniform unit-cube clouds; the reduction "
+                        "behind SamplesLoss('sinkhorn', backend='online'/'multiscale') (BASELINE configs[1]-[2]); one problem, one GPU",
+            "pairs_per_step": pairs_per_launch,
+            "parallelism": "single GPU",
+        },
+        "roofline": {
+            "bound": "valu", "achieved": kernel_pairs_s / 1e12, "peak": VALU_PEAK_PAIRS_PER_S / 1e12, "unit": "Tpair/s",
+            "frac": kernel_pairs_s / VALU_PEAK_PAIRS_PER_S, "traffic": None,
+            "model": "VALU issue: 1 v_exp_f32 (quarter rate, 8 cycles per wave64) + 1 v_add_f32 (2 cycles) per pair, the bf16x3 "
+                     "MFMA that forms the exponent co-issues -> 10 SIMD cycles per 64 pairs; 256 CU x 4 SIMD x 2.4 GHz",
+            "kernel": "softmin_fwd_x32_kernel (+ pack_columns_kernel + merge_kernel: one glhip_softmin_fwd call; the x32 kernel is "
+                      "> 99.9 % of it)",
+            "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
+            "frac_of_measured_stream": kernel_pairs_s / (SIMDS * CLOCK_HZ * 64 / MEASURED_STREAM_CYCLES),
+            "measured_stream": f"{MEASURED_STREAM_CYCLES} cycles per 64 pairs: the same exp2 + add instruction stream micro-benchmarked "
+                               "alone on this part (profiles/r01_ubench_pipes.txt)",
+            "hbm_dense_equivalent": {
+                "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dense_gbs / HBM_PEAK_GBS,
+                "model": "BASELINE.json's figure (SURVEY §8d-1): 4 algorithmic bytes per pair = the fp32 cost entry the tensorized "
+                         "formulation streams; > 1 because this kernel never materialises the matrix — not a physical HBM rate",
+            },
+            "compulsory_bytes_per_launch": compulsory, "compulsory_GBs": compulsory / (kernel_ms * 1e-3) / 1e9,
+            "builder_pmc": builder_pmc,
+        },
+    }
+    if not args.no_extras:
+        for key, fn in (("kernels", lambda: hot_path_kernels(dev, n)), ("cpu_baseline", cpu_baseline),
+                        ("sinkhorn_wallclock", lambda: sinkhorn_wallclock(dev)),
+                        ("sharded_batch_reference", lambda: sharded_reference(dev))):
+            try:
+                res[key] = fn()
+            except Exception as e:   # never lose the GPU number to a side leg
+                res[key] = {"error": repr(e)}
+                if key == "cpu_baseline":
+                    res[key].update(value=None, unit="pairs/s", cores=os.cpu_count(), kind="port", sample="failed")
+    print(json.dumps(res), flush=True)
+
+
+def run_sharded(args, dev, rank, world):
+    """BASELINE configs[3]: B = 256 problems sharded over the ranks through ShardedSamplesLoss."""
+    import torch.distributed as dist
+    from geomloss_amd import SamplesLoss
+    from geomloss_amd.distributed import ShardedSamplesLoss, shard_bounds
+
+    B = args.batch
+    lo, hi = shard_bounds(B, rank, world)
+    # every rank draws the whole batch from the same seed and keeps its slice: the global problem does not depend on N
+    x, y = cfg4_batch(torch.device("cpu"), B, seed=2)
+    x, y = x[lo:hi].to(dev), y[lo:hi].to(dev)
+    loss = ShardedSamplesLoss(SamplesLoss("sinkhorn", backend="online", **CFG4), reduction="sum")
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss(x, y)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = loss(x, y)          # local batched loss + scalar all-reduce (RCCL over xGMI)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    if rank == 0:
+        pairs = cfg4_pairs(B)
+        print(json.dumps({
+            "metric": "softmin pairs/s of the batch-sharded Sinkhorn loss (BASELINE configs[3]: B=256, N=M=4096 3D bf16)",
+            "value": pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16 points, f32 dual variables and accumulation", "data": "synthetic",
+            "config": {
+                "workload": f"ShardedSamplesLoss(SamplesLoss('sinkhorn', p=2, blur=.05, diameter=1.8, backend='online')), B={B} x 4096 x 4096 "
+                            f"3D bf16, {hi - lo} problems on rank 0; one step = one forward loss of the whole batch",
+                "pairs_per_step": pairs, "global_batch": B,
+                "parallelism": f"batch sharded x{world} (contiguous slices), no data-path collective, one scalar all-reduce per step "
+                               f"({args.backend})",
+                "single_gpu_point": "`sharded_batch_reference` of the N=1 line (same workload, whole batch on one GPU)",
+            },
+            "loss_sum": float(total),
+        }), flush=True)
 
 
 def main():
@@ -146,8 +355,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=1_000_000, help="N = M of the soft-min workload")
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the Sinkhorn wall-clock legs")
+    ap.add_argument("--points", type=int, default=1_000_000, help="N = M of the soft-min workload (N = 1)")
+    ap.add_argument("--batch", type=int, default=256, help="global batch of the sharded workload (N > 1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs (kernels, cpu_baseline, wall-clocks)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU dry run)")
     ap.add_argument("--single-device", action="store_true",
                     help="dry run of the N>1 path on a 1-GPU box: every rank uses cuda:0 (only with --backend gloo)")
@@ -163,113 +373,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from geomloss_amd import hip
     hip.load_library()   # raises if the HIP extension is missing: there is no fallback to time
 
-    n = args.points
-    x, y, h, eps = make_problem(n, dev, seed=1000 + rank)
-
-    def step():
-        out = hip.softmin_fwd_raw(x, y, h, eps, 2)
-        if world > 1:
-            s = out.sum()
-            dist.all_reduce(s)   # scalar batch-loss reduction over xGMI
-        return out
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts[k].record()               # same stream as the launch (torch's current stream)
-        out = hip.softmin_fwd_raw(x, y, h, eps, 2)
-        stops[k].record()
-        if world > 1:
-            s = out.sum()
-            dist.all_reduce(s)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(starts, stops)) / args.steps
-
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    if rank == 0:
-        pairs_per_launch = float(n) * n
-        value = world * pairs_per_launch * args.steps / elapsed
-        kernel_pairs_s = pairs_per_launch / (kernel_ms * 1e-3)
-        achieved = kernel_pairs_s * 4 / 1e9
-        traffic, pipes = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_softmin.json")
-        if os.path.exists(pmc):   # counters of this same command, collected by tools/profile_gpu.sh (separate --pmc passes)
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get("hbm_bytes_per_launch")
-                pipes = {k: pj.get(k) for k in ("VALUBusy_per_launch", "MfmaUtil_per_launch", "effective_clock_GHz", "l2_hit_rate")}
-            except Exception:
-                traffic = None
-        compulsory = 4.0 * (n * 3 + n * 4 + n)
-        res = {
-            "metric": "softmin pairs/s, N=M=1e6 3D fp32 (Sinkhorn wall-clock: `sinkhorn_wallclock`; % HBM roofline: `roofline`)"
-                      if n == 1_000_000 else f"softmin pairs/s (N=M={n} 3D fp32)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"glhip_softmin_fwd dense, N=M={n}, D=3, p=2, eps=0.05^2, uniform unit-cube clouds; "
-                            "the reduction behind SamplesLoss('sinkhorn', backend='online'/'multiscale') "
-                            "(BASELINE configs[1]-[2]); one problem per GPU",
-                "pairs_per_step_per_gpu": pairs_per_launch,
-                "parallelism": f"batch-sharded x{world}, scalar all-reduce per step" if world > 1 else "single GPU",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "model": "dense-equivalent: 4 algorithmic bytes per pair (SURVEY §8d); the kernel is issue-bound (exp2 + MFMA), "
-                         "frac > 1 means it beats what any kernel streaming the fp32 cost matrix could reach",
-                "kernel": "pack_columns_kernel + softmin_fwd_x32_kernel<3,float,false,1,8,true> + merge_kernel (one "
-                          "glhip_softmin_fwd call; the x32 kernel is > 99.9 % of it)",
-                "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
-                "compulsory_bytes_per_launch": compulsory, "compulsory_GBs": compulsory / (kernel_ms * 1e-3) / 1e9,
-                "pmc": pipes,
-                "issue_model_frac": kernel_pairs_s / ISSUE_CEILING_PAIRS_PER_S,
-                "issue_model": f"{ISSUE_CYCLES_PER_64_PAIRS:.2f} SIMD cycles per 64 pairs = the exp2 + add stream alone (16 v_exp_f32 + "
-                               f"16 v_add_f32 per 1024 pairs, micro-benchmarked, MFMA hidden) -> {ISSUE_CEILING_PAIRS_PER_S:.3g} pairs/s at "
-                               f"2.4 GHz; the bare inner loop (chained 32x32x16 MFMA pair + that stream) measures "
-                               f"{LOOP_CYCLES_PER_64_PAIRS} cycles -> {256 * 4 * 2.4e9 * 64 / LOOP_CYCLES_PER_64_PAIRS:.3g} pairs/s",
-            },
-        }
-        if world == 1 and not args.no_extras:
-            try:
-                res["cpu_baseline"] = cpu_baseline()
-            except Exception as e:   # never lose the GPU number to a host-side problem
-                res["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
-            try:
-                res["sinkhorn_wallclock"] = sinkhorn_wallclock(dev)
-            except Exception as e:
-                res["sinkhorn_wallclock"] = {"error": repr(e)}
-        print(json.dumps(res), flush=True)
-
-    if world > 1:
+    if world == 1:
+        run_headline(args, dev)
+        return
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    try:
+        run_sharded(args, dev, rank, world)
+    finally:
         dist.destroy_process_group()
 
 

@@ -148,3 +148,24 @@ def test_torch64_reductions_match_numpy_oracle(p):
             assert relerr(oracle_torch64.kconv(kind, x, y, v, blur, device=CPU, budget=60_000), ref) < 1e-12
             gref = oracle_c.kconv_grad_x(kind, x, y, v, g, blur)
             assert relerr(oracle_torch64.kconv_grad_x(kind, x, y, v, g, blur, device=CPU, budget=60_000), gref) < 1e-11
+
+
+def test_torch_port_matches_reference():
+    """oracle/tensorized_torch.py — the PyTorch-CPU port timed as ``cpu_baseline`` by bench.py — against the reference's own
+    fp32 tensorized outputs: BASELINE configs[0] exactly, and two 3-D golden cases (uniform weights)."""
+    from oracle.tensorized_torch import sinkhorn_tensorized_cpu
+
+    rec = load_golden("cfg1_n2000_d2")
+    cnt = {}
+    L = sinkhorn_tensorized_cpu(torch.from_numpy(rec["x"])[None], torch.from_numpy(rec["y"])[None], count=cnt).item()
+    assert abs(L - float(rec["loss_f32"])) <= 2e-5 * float(rec["loss_f32"])     # fp32 vs fp32: summation order only
+    assert abs(L - float(rec["loss_f64"])) <= 1e-4 * float(rec["loss_f64"])
+    assert cnt["softmin_calls"] == 36                                            # 4 + 4 * 7 + 4 (SURVEY App. A, D=2 unit square)
+    for name in ("sinkhorn_p2_d2", "sinkhorn_p2_scaling9"):                       # the uniform-weight golden cases
+        rec = load_golden(name)
+        kw = rec["kwargs"]
+        x, y = torch.from_numpy(rec["x"])[None], torch.from_numpy(rec["y"])[None]
+        L64 = sinkhorn_tensorized_cpu(x, y, p=kw["p"], blur=kw["blur"], scaling=kw.get("scaling", 0.5)).item()
+        assert abs(L64 - float(rec["loss_f64"])) <= 1e-9 * abs(float(rec["loss_f64"]))
+        L32 = sinkhorn_tensorized_cpu(x.float(), y.float(), p=kw["p"], blur=kw["blur"], scaling=kw.get("scaling", 0.5)).item()
+        assert abs(L32 - float(rec["loss_f32"])) <= 2e-5 * abs(float(rec["loss_f32"]))

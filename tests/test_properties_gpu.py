@@ -186,3 +186,29 @@ def test_fused_iterations_reproduce_the_per_softmin_loop(cuda, kw):
         # bf16 points get bf16 gradients: the two paths may round a value to neighbouring bf16 numbers (1 ulp = 2^-8)
         gtol = 2e-5 if dtype == torch.float32 else 2 ** -7
         assert (g1 - g0).abs().max().item() <= gtol * g0.abs().max().item() + 1e-9
+
+
+def test_bench_sharded_path_two_ranks_on_one_gpu(cuda):
+    """`bench.py --gpus 2` — the N > 1 leg the driver launches on a multi-GPU node (BASELINE configs[3] through
+    ShardedSamplesLoss) — exercised here with two processes sharing cuda:0 over gloo; its loss must equal the unsharded one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6",
+           "--backend", "gloo", "--single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["global_batch"] == 6
+    sys.path.insert(0, root)
+    import bench
+    x, y = bench.cfg4_batch(cuda, 6, seed=2)
+    ref = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)(x, y).sum().item()
+    assert abs(rec["loss_sum"] - ref) <= 1e-6 * abs(ref)
+    assert abs(rec["config"]["pairs_per_step"] - 6 * 40 * 4096.0**2) < 1
