@@ -20,5 +20,6 @@ from . import hip
 # is also callable, and calling it runs the image-OT function of that name (sinkhorn_images.sinkhorn_divergence).
 from .wasserstein_barycenter_images import ImagesBarycenter  # noqa: E402
 from . import sinkhorn_divergence  # noqa: E402
+from . import ot  # noqa: E402  (`from geomloss import ot`: ot.solve_sample on the same kernels)
 
-__all__ = ["SamplesLoss", "ImagesBarycenter", "sinkhorn_divergence", "hip"]
+__all__ = ["SamplesLoss", "ImagesBarycenter", "sinkhorn_divergence", "hip", "ot"]

@@ -34,28 +34,33 @@ def grid_cluster(x, size):
     return lab.int()
 
 
-def cluster_ranges_centroids(x, lab, weights=None, min_weight=1e-9):
+def cluster_ranges_centroids(x, lab, weights=None, min_weight=1e-9, perm=None):
     """Per-cluster [start, end) ranges (valid once the cloud is sorted by label), weighted centroids, total weights.
 
     Sums are segment sums of the label-sorted cloud, taken as differences of a float64 inclusive scan: deterministic
     (no atomics — the same inputs give the same centroids bit for bit on every run) and exact to ~1e-16 of the total
     mass.  Weights keep their own precision (fp32 for bf16 / fp16 clouds); centroids come back in the dtype of ``x``.
+    ``perm``: the stable argsort of ``lab`` when the caller already has it.
     """
     lab = lab.long().view(-1)
     counts = torch.bincount(lab)          # integer histogram: exact, order-independent
     ends = counts.cumsum(0)
     ranges = torch.stack((ends - counts, ends), dim=1).int()
     wdtype = torch.float32 if weights is None or weights.dtype in (torch.bfloat16, torch.float16) else weights.dtype
-    if x.shape[0] == 0:
-        return ranges, x.new_zeros((0, x.shape[1])), torch.zeros(0, dtype=wdtype, device=x.device)
-    perm = torch.sort(lab, stable=True)[1]
-    w = (torch.ones(x.shape[0], dtype=torch.float64, device=x.device) if weights is None
-         else weights.view(-1).double())[perm]
-    vals = torch.cat((w.unsqueeze(1), w.unsqueeze(1) * x.double()[perm]), dim=1)   # (N, 1 + D)
-    scan = torch.cat((vals.new_zeros((1, vals.shape[1])), vals.cumsum(0)), dim=0)
-    seg = scan[ends] - scan[ends - counts]                                          # (C, 1 + D)
-    w_c = seg[:, 0]
-    cents = seg[:, 1:] / w_c.clamp_min(min_weight).unsqueeze(1)
+    N, D = x.shape
+    if N == 0:
+        return ranges, x.new_zeros((0, D)), torch.zeros(0, dtype=wdtype, device=x.device)
+    if perm is None:
+        perm = torch.sort(lab, stable=True)[1]
+    # (1 + D, N) rows [w, w x_1, ..., w x_D] of the sorted cloud; the scan runs along the contiguous axis
+    vals = torch.empty((1 + D, N), dtype=torch.float64, device=x.device)
+    vals[0] = 1.0 if weights is None else weights.view(-1)[perm]
+    vals[1:] = x[perm].t()
+    vals[1:] *= vals[0]
+    scan = torch.cat((vals.new_zeros((1 + D, 1)), vals.cumsum(1)), dim=1)
+    seg = scan[:, ends] - scan[:, ends - counts]                                     # (1 + D, C)
+    w_c = seg[0]
+    cents = (seg[1:] / w_c.clamp_min(min_weight)).t().contiguous()
     return ranges, cents.to(x.dtype), w_c.to(wdtype)
 
 

@@ -266,8 +266,8 @@ def clusterize(a, x, scale=None, labels=None):
     if labels is None and scale is None:
         return [a], [x], []
     x_lab = grid_cluster(x, scale) if labels is None else labels
-    ranges_x, x_c, a_c = cluster_ranges_centroids(x, x_lab, weights=a)
     _, perm = torch.sort(x_lab.view(-1), stable=True)
+    ranges_x, x_c, a_c = cluster_ranges_centroids(x, x_lab, weights=a, perm=perm)
     return [a_c, a[perm]], [x_c, x[perm]], [ranges_x], perm
 
 

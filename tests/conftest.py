@@ -25,11 +25,15 @@ def golden_cases(mid=False):
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
-        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_")):
+        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_", "ot_")):
             continue   # special cases, and the grid-path vectors of make_golden_images.py (tests/test_images_*.py)
         if name not in MID_SIZE:
             out.append(name)
     return out
+
+
+def ot_golden_cases():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, "ot_*.npz")))
 
 
 def load_golden(name):

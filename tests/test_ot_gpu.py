@@ -1,0 +1,149 @@
+"""``geomloss_amd.ot.solve_sample`` on the HIP kernels: against outputs of the reference's own solver (tests/golden/ot_*.npz),
+against the closed forms the reference's test-suite uses (``/root/reference/tests/test_ot_solve_sample.py`` with
+``generators/diracs.py:75-147``: one point on each side; ``generators/permutations.py``: matched points), and the
+matrix-free plan operators against the dense plan."""
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings
+from hypothesis import strategies as st
+from hypothesis.extra.numpy import arrays as st_arrays
+
+from conftest import load_golden, ot_golden_cases, relerr
+from geomloss_amd import ot
+from oracle import oracle_ot
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ot_golden_cases())
+def test_solve_sample_matches_reference(cuda, name):
+    rec = load_golden(name)
+    res = ot.solve_sample(rec["x"], rec["y"], a=rec.get("a"), b=rec.get("b"), **rec["kwargs"])
+    assert isinstance(res.value, np.ndarray) and res.value.shape == () and res.value.dtype == np.float64
+    assert abs(float(res.value) - float(rec["value"])) <= 1e-4 * abs(float(rec["value"]))
+    scale = max(np.abs(rec["potential_a"]).max(), np.abs(rec["potential_b"]).max())
+    for k in ("potential_a", "potential_b", "potential_aa", "potential_bb"):
+        if k in rec:
+            got = getattr(res, k)
+            assert got.shape == rec[k].shape and got.dtype == np.float64
+            assert np.abs(got - rec[k]).max() <= 1e-4 * scale, k
+    for k in ("marginal_a", "marginal_b"):
+        assert relerr(getattr(res, k), rec[k]) < 1e-4, k
+    if "plan" in rec:
+        assert relerr(res.plan, rec["plan"]) < 1e-4
+    else:
+        assert relerr(res.plan[:5], rec["plan_rows"]) < 1e-4
+
+
+@given(D=st.integers(1, 5), data=st.data(), max_iter=st.integers(1, 50), reg=st.floats(1e-2, 10.0),
+       library=st.sampled_from(["numpy", "torch"]), dtype=st.sampled_from(["float32", "float64"]),
+       device=st.sampled_from(["cpu", "cuda"]), weights=st.booleans())
+@settings(deadline=None, max_examples=40)
+def test_correct_values_diracs(D, data, max_iter, reg, library, dtype, device, weights):
+    """One source point, one target point: value = |x - y|^2, plan = [[1]], potentials = value / 2 each, for any temperature
+    and any number of iterations; results come back in the caller's library, dtype and device."""
+    pts = st_arrays(np.float64, (1, D), elements=st.floats(-10, 10))
+    x, y = data.draw(pts), data.draw(pts)
+    a = np.ones(1) if weights else None
+
+    def cast(v):
+        if v is None:
+            return None
+        v = v.astype(dtype)
+        return torch.from_numpy(v).to(device) if library == "torch" else v
+
+    res = ot.solve_sample(cast(x), cast(y), a=cast(a), b=cast(a), reg=reg, max_iter=max_iter)
+    C = float(((x - y) ** 2).sum())
+
+    def check(got, want, shape):
+        if library == "torch":
+            assert isinstance(got, torch.Tensor) and got.device.type == device and str(got.dtype) == "torch." + dtype
+            got = got.cpu().numpy()
+        else:
+            assert isinstance(got, np.ndarray) and str(got.dtype) == dtype
+        assert got.shape == shape
+        assert np.allclose(got, want, atol=1e-2)
+
+    check(res.value, C, ())
+    check(res.plan, 1.0, (1, 1))
+    check(res.potential_a + res.potential_b[0], C, (1,))
+    check(res.potential_a - res.potential_b, 0.0, (1,))
+
+
+@pytest.mark.parametrize("N,D", [(40, 2), (300, 3)])
+def test_correct_values_permutations(cuda, N, D):
+    """Target = a shuffled copy of the source moved by a small, constant shift: for a small temperature the plan is the
+    permutation matrix / N and the value the squared shift (closed form of generators/permutations.py)."""
+    rng = np.random.default_rng(N)
+    x = rng.random((N, D))
+    perm = rng.permutation(N)
+    shift = np.full(D, 0.01)
+    y = x[perm] + shift
+    res = ot.solve_sample(x, y, reg=1e-4, max_iter=100)
+    expected = np.zeros((N, N))
+    expected[perm, np.arange(N)] = 1.0 / N
+    assert np.abs(res.plan - expected).max() < 1e-3 / N
+    assert abs(float(res.value) - float((shift**2).sum())) < 1e-4
+    assert np.allclose(res.marginal_a, 1.0 / N, rtol=1e-3) and np.allclose(res.marginal_b, 1.0 / N, rtol=1e-3)
+
+
+def test_doctest_example_of_the_reference(cuda):
+    """The example in the reference's docstring (sample.py:256-279)."""
+    sol = ot.solve_sample(X_a=[[0, 0], [0, 2]], X_b=[[2, 1], [2, 2]], reg=0.001, max_iter=100)
+    assert np.allclose(sol.plan, [[0.5, 0.0], [0.0, 0.5]], atol=1e-3)
+    assert f"{float(sol.value):.3f}" == "4.501"
+
+
+def test_operators_match_the_dense_plan(cuda):
+    rec = load_golden("ot_unbalanced_d2")
+    x, y, a, b = (torch.from_numpy(rec[k]).float().to(cuda) for k in ("x", "y", "a", "b"))
+    res = ot.solve_sample(x, y, a=a, b=b, **rec["kwargs"])
+    P, dens = res.plan, res.density
+    assert P.device.type == "cuda" and P.dtype == torch.float32 and P.shape == (x.shape[0], y.shape[0])
+    g = torch.Generator().manual_seed(0)
+    v, V = torch.randn(y.shape[0], generator=g).to(cuda), torch.randn(y.shape[0], 3, generator=g).to(cuda)
+    u = torch.randn(x.shape[0], generator=g).to(cuda)
+    for op, dense in ((res.plan_operator, P), (res.lazy_plan, P), (res.density_operator, dens), (res.lazy_density, dens)):
+        assert op.shape == tuple(dense.shape)
+        assert relerr((op @ v).cpu().numpy(), (dense @ v).cpu().numpy()) < 1e-4
+        assert relerr((op @ V).cpu().numpy(), (dense @ V).cpu().numpy()) < 1e-4
+        assert relerr((op.T @ u).cpu().numpy(), (dense.t() @ u).cpu().numpy()) < 1e-4
+    assert relerr(res.marginal_a.cpu().numpy(), P.sum(1).cpu().numpy()) < 1e-4
+    assert relerr(res.marginal_b.cpu().numpy(), P.sum(0).cpu().numpy()) < 1e-4
+    with pytest.raises(ValueError, match="run your OT solver with `debias = True`"):
+        res.potential_aa
+
+
+def test_softmin_sample_branches(cuda):
+    rng = np.random.default_rng(3)
+    x, y = rng.random((50, 3)), rng.random((60, 3))
+    b = rng.random(60) + 0.1
+    g = rng.standard_normal(60) * 0.1
+    xt, yt, lb, gt = (torch.from_numpy(v).float().to(cuda) for v in (x, y, np.log(b), g))
+    C = oracle_ot.cost_matrix(x, y)
+    for eps in (float("inf"), 0.3, 0.01):
+        got = ot.softmin_sample(eps, lb, (xt, yt), gt).cpu().numpy()
+        assert relerr(got, oracle_ot.softmin(eps, np.log(b), C, g)) < 2e-5, eps
+    with pytest.raises(NotImplementedError):
+        ot.softmin_sample(0, lb, (xt, yt), gt)
+
+
+def test_large_problem_and_gradient(cuda):
+    """Value and potentials against the float64 oracle at N = 1500, and the gradient of the value in X_a against the oracle's
+    closed form (autograd sees the last soft-min only; the column cloud and the dual vector are detached)."""
+    rng = np.random.default_rng(11)
+    N, M = 1500, 1400
+    x, y = rng.random((N, 3)), rng.random((M, 3)) * 0.7 + 0.2
+    kw = dict(reg=0.02, max_iter=30)
+    ref = oracle_ot.solve_sample(x, y, **kw)
+    xt = torch.from_numpy(x).float().to(cuda).requires_grad_(True)
+    yt = torch.from_numpy(y).float().to(cuda)
+    res = ot.solve_sample(xt, yt, **kw)
+    assert abs(res.value.item() - ref["value"]) <= 1e-4 * abs(ref["value"])
+    assert relerr(res.potential_a.detach().cpu().numpy(), ref["potential_a"]) < 1e-4
+    (gx,) = torch.autograd.grad(res.value, [xt])
+    # balanced, no debias: value = <a, f_ba> + <b, g_ab>, and only f_ba's last soft-min sees x as its row cloud
+    grad_ref = ref["grad_f_ba"] / N
+    assert relerr(gx.cpu().numpy(), grad_ref) < 1e-4
