@@ -84,7 +84,9 @@ def test_correct_values_permutations(cuda, N, D):
     res = ot.solve_sample(x, y, reg=1e-4, max_iter=100)
     expected = np.zeros((N, N))
     expected[perm, np.arange(N)] = 1.0 / N
-    assert np.abs(res.plan - expected).max() < 1e-3 / N
+    # fp32 potentials carry ~1e-7 absolute error; divided by reg = 1e-4 that is ~1e-3 relative on a plan entry
+    # (the reference's own permutation test accepts atol = rtol = 5e-2, generators/permutations.py:66-69)
+    assert np.abs(res.plan - expected).max() < 5e-3 / N
     assert abs(float(res.value) - float((shift**2).sum())) < 1e-4
     assert np.allclose(res.marginal_a, 1.0 / N, rtol=1e-3) and np.allclose(res.marginal_b, 1.0 / N, rtol=1e-3)
 
