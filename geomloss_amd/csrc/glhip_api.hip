@@ -56,10 +56,28 @@ struct Scratch {
     size_t bytes;
     bool allow_split;
     bool force_pre;     // GLHIP_FLAG_PREPACK
+    ChunkBuf cb;        // block-sparse launches: room for the row-chunk table, carved off the front of the workspace
     // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
     // GLHIP_FLAG_NO_SPLIT tells us to leave alone
     bool prepack(double pairs) const { return ws && (force_pre || (allow_split && pairs >= 5e8)); }
 };
+
+// Scratch of one API call.  Block-sparse calls reserve the front of the workspace for the row-chunk table (sized for the
+// smallest row tile, 128 rows); the rest serves the column splits and the packed columns as before.
+Scratch make_scratch(void* workspace, size_t bytes, int flags, int n_ranges, int N) {
+    Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0, ChunkBuf()};
+    if (n_ranges > 0 && workspace) {
+        const size_t need = chunk_table_bytes(n_ranges, N, 128);
+        if (bytes >= need) {
+            sc.cb.buf = static_cast<int32_t*>(workspace);
+            sc.cb.capacity = (long)n_ranges + N / 128 + 1;
+            sc.ws = static_cast<char*>(workspace) + need;
+            sc.bytes = bytes - need;
+            if (sc.bytes == 0) sc.ws = nullptr;
+        }
+    }
+    return sc;
+}
 
 // rows per thread: 2 keeps the LDS read rate at half a ds_read_b128 per row-column step while leaving
 // enough workgroups to fill 256 CUs; small problems use 1 to expose more workgroups.
@@ -76,11 +94,11 @@ template <int D, int P, bool DIRECT, bool BWD, typename T>
 void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                       const Scratch& sc, hipStream_t st) {
     if (use_two_rows(B, N, n_ranges, sc)) {
-        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
-        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
     } else {
-        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
-        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        if (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
     }
 }
 
@@ -107,7 +125,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
     constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
     static_assert(kFwdRT == 2, "row tiling of the forward kernels");
-    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
+    unsigned chunk_grid = 0;   // block-sparse: one workgroup per row chunk of kRowsPerBlock rows (build_row_chunks_kernel)
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)chunk_grid : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
     const long per_split = (long)B * N * 2 * sizeof(float);
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
@@ -156,9 +176,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (n_ranges > 0) {
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(n_ranges, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
         } else {
-            launch_fwd_kernel<D, T, KIND, NW, true>(dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp);
+            launch_fwd_kernel<D, T, KIND, NW, true>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -217,7 +237,9 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and MFMA kernel must tile rows alike");
     static_assert(WsumShape<MODE, D>::kPart == MergeOp::kPartial, "partial formats differ");
     constexpr int NQ = WsumShape<MODE, D>::kNQ;
-    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
+    unsigned chunk_grid = 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kMfmaRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)chunk_grid : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
     const long per_split = (long)B * N * MergeOp::kPartial * sizeof(float);
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
@@ -262,7 +284,7 @@ void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm,
     }
     const bool pre = plan_pre(sp.n_splits);
     if (n_ranges > 0) {
-        launch_wsum_kernel<MODE, D, T, true>(x32, pre, dim3(n_ranges, 1, sp.n_splits), st, prm, rg, N, M, sp, pk, pq);
+        launch_wsum_kernel<MODE, D, T, true>(x32, pre, dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp, pk, pq);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
@@ -443,9 +465,9 @@ template <int KIND, int D, bool BWD, typename T>
 void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
                    hipStream_t st) {
     if (use_two_rows(B, N, n_ranges, sc))
-        launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
     else
-        launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st);
+        launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
 }
 
 template <int KIND, bool BWD, typename T>
@@ -582,6 +604,7 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
                           (size_t)B * (size_t)((M + 31) / 32) * 2048 + (size_t)4 * B * M * sizeof(float);
         bytes = bytes > ws ? bytes : ws;
     }
+    if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);   // row-chunk table of block-sparse launches
     return bytes;
 }
 
@@ -599,7 +622,7 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     rc = (in_dtype == GLHIP_F32)
              ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
              : softmin_typed<false, bf16_t>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
@@ -619,7 +642,7 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     StepArgs step;
     step.pot = pot;
     step.prev = prev;
@@ -650,7 +673,7 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
         return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: outputs must not alias inputs (updates are simultaneous)");
     if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_iter4: eps must be > 0");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, false};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags & ~GLHIP_FLAG_PREPACK, 0, N);
     rc = (in_dtype == GLHIP_F32)
              ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st)
              : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st);
@@ -706,7 +729,7 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const floa
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_bwd_x: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     rc = (in_dtype == GLHIP_F32)
              ? softmin_typed<true, float>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
              : softmin_typed<true, bf16_t>(x, y, h, nullptr, out, grad_out, grad_x, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st);
@@ -725,7 +748,7 @@ int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     rc = (in_dtype == GLHIP_F32)
              ? conv_typed<false, float>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
              : conv_typed<false, bf16_t>(kind, x, y, v, out, nullptr, nullptr, B, N, M, D, blur, rg, n_ranges, sc, flags, st);
@@ -744,7 +767,7 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Scratch sc{workspace, workspace_bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0};
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     rc = (in_dtype == GLHIP_F32)
              ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
              : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st);

@@ -37,6 +37,9 @@ struct Ranges {
     const int32_t* ranges_i;
     const int32_t* slices_i;
     const int32_t* redranges_j;
+    // optional row-chunk table built by build_row_chunks_kernel (glhip_mapreduce.h): chunks[0] = number of chunks T, then
+    // T triplets (row block k, first row, end row).  NULL: one workgroup per row block (the KeOps granularity).
+    const int32_t* chunks;
 };
 
 // One LDS record per column point: D coordinates (already centred / scaled) + one scalar.

@@ -64,9 +64,16 @@ template <bool SPARSE>
 __device__ __forceinline__ void block_extent(const Ranges& rg, int N, int rows_per_pass, int& row_begin,
                                              int& row_end, int& q_begin, int& q_end, int bx = blockIdx.x) {
     if (SPARSE) {
-        const int k = bx;
-        row_begin = rg.ranges_i[2 * k];
-        row_end = rg.ranges_i[2 * k + 1];
+        int k = bx;
+        if (rg.chunks) {   // row blocks cut into chunks of at most `rows_per_pass` rows: workgroup bx owns chunk bx
+            if (bx >= rg.chunks[0]) { row_begin = row_end = q_begin = q_end = 0; return; }
+            k = rg.chunks[1 + 3 * bx];
+            row_begin = rg.chunks[2 + 3 * bx];
+            row_end = rg.chunks[3 + 3 * bx];
+        } else {
+            row_begin = rg.ranges_i[2 * k];
+            row_end = rg.ranges_i[2 * k + 1];
+        }
         q_begin = (k == 0) ? 0 : rg.slices_i[k - 1];
         q_end = rg.slices_i[k];
     } else {
@@ -88,6 +95,48 @@ __device__ __forceinline__ void column_interval(const Ranges& rg, int M, int q, 
         js = min(M, s * len);
         je = min(M, js + len);
     }
+}
+
+// Row-chunk table of a block-sparse launch.  The KeOps convention gives one workgroup per row block (cluster); voxel clusters
+// of real clouds are very uneven (a sphere sampled at 1e6 points: 1 ... 19 566 rows per cluster), so the workgroup of the
+// biggest cluster runs long after the chip has drained.  This single-workgroup kernel cuts every row block into chunks of
+// `rows` rows (the row tile of the kernel that follows) with a block-wide prefix sum over the clusters, so that the grid of
+// the reduction is one workgroup per chunk: chunks[0] = T, chunks[1 + 3c ...] = (row block, first row, end row).  The host
+// only knows the bound T <= n_ranges + N / rows and launches that many workgroups; the surplus exits at once.
+__global__ void __launch_bounds__(1024)
+build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int rows, int32_t* __restrict__ chunks, int capacity) {
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_ranges; base += 1024) {
+        const int k = base + tid;
+        int r0 = 0, r1 = 0;
+        if (k < n_ranges) { r0 = ranges_i[2 * k]; r1 = ranges_i[2 * k + 1]; }
+        const int cnt = (r1 > r0) ? (r1 - r0 + rows - 1) / rows : 0;
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {   // inclusive Hillis-Steele scan
+            const int v = (tid >= off) ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int first = carry + scan[tid] - cnt;
+        for (int c = 0; c < cnt; ++c) {
+            const int slot = first + c;
+            if (slot < capacity) {
+                chunks[1 + 3 * slot] = k;
+                chunks[2 + 3 * slot] = r0 + c * rows;
+                chunks[3 + 3 * slot] = min(r1, r0 + (c + 1) * rows);
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) chunks[0] = min(carry, capacity);
 }
 
 template <class Op, bool SPARSE>
@@ -199,12 +248,38 @@ static inline int xcd_splits_prepacked(long row_blocks, int M, long slots, long 
     return ns;
 }
 
+// Space reserved at the front of the caller's workspace for the row-chunk table of a block-sparse launch.
+struct ChunkBuf {
+    int32_t* buf = nullptr;
+    long capacity = 0;      // chunks the table can hold
+};
+
+static inline size_t chunk_table_bytes(int n_ranges, int N, int rows) {
+    return (((size_t)(1 + 3 * ((size_t)n_ranges + (size_t)N / rows + 1)) * sizeof(int32_t)) + 255) & ~(size_t)255;
+}
+
+// Queues build_row_chunks_kernel for a reduction whose workgroups take `rows` rows and returns the ranges to hand to it
+// together with its grid.x; without a reserved table (no workspace) the launch keeps one workgroup per row block.
+static inline Ranges with_row_chunks(const Ranges& rg, int n_ranges, int N, int rows, const ChunkBuf& cb, hipStream_t stream,
+                                     unsigned& grid_x) {
+    grid_x = (unsigned)n_ranges;
+    const long bound = (long)n_ranges + N / rows;
+    if (!cb.buf || cb.capacity < bound || n_ranges <= 0) return rg;
+    hipLaunchKernelGGL(build_row_chunks_kernel, dim3(1), dim3(1024), 0, stream, rg.ranges_i, n_ranges, rows, cb.buf, (int)bound);
+    Ranges out = rg;
+    out.chunks = cb.buf;
+    grid_x = (unsigned)bound;
+    return out;
+}
+
 template <class Op>
 static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges& rg, int n_ranges, int B, int N,
                                     int M, void* workspace, size_t workspace_bytes, bool allow_split,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, const ChunkBuf& cb = ChunkBuf()) {
     const int rows_per_block = kBlock * Op::kRows;
-    const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + rows_per_block - 1) / rows_per_block);
+    unsigned chunk_grid = 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, rows_per_block, cb, stream, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)chunk_grid : (long)B * ((N + rows_per_block - 1) / rows_per_block);
     const long per_split = (long)B * N * Op::kPartial * sizeof(float);
     const long fit = (workspace && per_split > 0) ? (long)(workspace_bytes / per_split) : 0;
     SplitInfo sp;
@@ -214,8 +289,8 @@ static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges
     sp.xcd_grid_x = 0;
     sp.xcd_blocks = 0;
     if (n_ranges > 0) {
-        dim3 grid(n_ranges, 1, sp.n_splits);
-        hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rg, N, M, sp);
+        dim3 grid(chunk_grid, 1, sp.n_splits);
+        hipLaunchKernelGGL((mapreduce_kernel<Op, true>), grid, dim3(kBlock), 0, stream, prm, rgc, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<Op, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, stream, prm, rg, N, sp);
     } else {

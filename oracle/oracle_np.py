@@ -482,6 +482,62 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
     return (out, info) if return_info else out
 
 
+def kernel_multiscale(name, a, x, b, y, blur=0.05, truncate=5, diameter=None, cluster_scale=None, potentials=False,
+                      grad=False, return_info=False):
+    """Block-sparse kernel norm of kernel_samples.py:177-271 on dense masked matrices: clouds centred and rescaled by
+    1/blur (:207-211), voxel clusters of the rescaled clouds (:214-226) with alpha / beta-weighted centroids (:229-230), keep-mask
+    |c_i - c_j|^2 <= (truncate + cell diameter)^2 on the centroids (:244-252), then kernel_loss (:92-146) restricted to the
+    kept blocks.  Returns the loss, or the potentials — like the reference, in cluster-SORTED point order (``perm_x`` / ``perm_y``
+    are in ``info``) — optionally with dL/dx in the caller's order (gaussian / laplacian)."""
+    a, x, b, y = (np.asarray(t, np.float64) for t in (a, x, b, y))
+    if truncate is None or name == "energy":
+        out = kernel_loss(name, x, y, a, b, blur=blur, potentials=potentials)
+        if grad:
+            out = (out, kernel_loss_grad_x(name, x, y, a, b, blur=blur))
+        return (out, dict(kept_fraction=[1.0, 1.0, 1.0])) if return_info else out
+    N, D = x.shape
+    centre = (x.mean(0, keepdims=True) + y.mean(0, keepdims=True)) / 2
+    x, y = x - centre, y - centre
+    xs, ys = x / blur, y / blur
+    if cluster_scale is None:
+        diam = max_diameter(xs, ys) if diameter is None else diameter / blur
+        cluster_scale = diam / (np.sqrt(D) * 2000 ** (1 / D))
+    cell = cluster_scale * np.sqrt(D)
+    _, a_s, xc, xs_s, ranges_x, perm_x = clusterize(a, xs, cluster_scale)
+    _, b_s, yc, ys_s, ranges_y, perm_y = clusterize(b, ys, cluster_scale)
+    x_s, y_s = x[perm_x], y[perm_y]
+    reach2 = (truncate + cell) ** 2
+    M = y.shape[0]
+    m_xx = _expand_mask(squared_distances(xc, xc) <= reach2, ranges_x, ranges_x, N, N)
+    m_yy = _expand_mask(squared_distances(yc, yc) <= reach2, ranges_y, ranges_y, M, M)
+    m_xy = _expand_mask(squared_distances(xc, yc) <= reach2, ranges_x, ranges_y, N, M)
+    K_xx, K_yy, K_xy = (np.where(m, kernel_matrix(name, u, v, blur), 0.0)
+                        for m, u, v in ((m_xx, x_s, x_s), (m_yy, y_s, y_s), (m_xy, x_s, y_s)))
+    a_x, b_y, b_x = K_xx @ a_s, K_yy @ b_s, K_xy @ b_s
+    info = dict(kept_fraction=[float(m.mean()) for m in (m_xx, m_yy, m_xy)], perm_x=perm_x, perm_y=perm_y,
+                n_clusters=(len(xc), len(yc)))
+    if potentials:
+        out = (a_x - b_x, b_y - K_xy.T @ a_s)
+    else:
+        out = float(0.5 * a_s @ a_x + 0.5 * b_s @ b_y - a_s @ b_x)
+        if grad:     # dL/dx_i = a_i [ sum_j a_j dk(x_i,x_j) - sum_j b_j dk(x_i,y_j) ] over the kept pairs (DoubleGrad, :43-54)
+            def dk(u, v, w, mask):
+                diff = u[:, None, :] - v[None, :, :]
+                d2 = (diff * diff).sum(-1)
+                if name == "gaussian":
+                    coef = -np.exp(-d2 / (2 * blur**2)) / blur**2
+                else:
+                    live = d2 > 1e-8 * blur**2
+                    d = np.sqrt(np.where(live, d2, 1.0))
+                    coef = -np.exp(-d / blur) * np.where(live, 1.0 / d, 0.0) / blur
+                return ((np.where(mask, coef, 0.0) * w[None, :])[..., None] * diff).sum(1)
+            gs = a_s[:, None] * (dk(x_s, x_s, a_s, m_xx) - dk(x_s, y_s, b_s, m_xy))
+            gx = np.empty_like(gs)
+            gx[perm_x] = gs
+            out = (out, gx)
+    return (out, info) if return_info else out
+
+
 # --------------------------------------------------------------------------------------------------
 #  measures on regular grids  (_legacy/utils.py:64-279, sinkhorn_images.py, wasserstein_barycenter_images.py)
 # --------------------------------------------------------------------------------------------------

@@ -193,6 +193,55 @@ def test_softmin_block_sparse_prepacked_path(cuda):
     assert np.isposinf(outs[0][~live]).all()
 
 
+def test_block_sparse_very_uneven_row_blocks(cuda):
+    """Row blocks of 1 ... 6000 rows (voxel clusters of a cloud sampled on a surface look like this): the launch cuts them
+    into row chunks (build_row_chunks_kernel), one workgroup each.  Forward, gradient, gaussian product and gradient against
+    the C oracle; with and without a workspace (no table: one workgroup per row block)."""
+    rng = np.random.default_rng(31)
+    sizes_i = np.array([1, 6000, 2, 1, 700, 3, 257, 256, 1, 1300, 5, 64], dtype=np.int64)
+    sizes_j = np.array([900, 1, 1, 4000, 2, 300, 31, 1, 1200], dtype=np.int64)
+    N, M, D = int(sizes_i.sum()), int(sizes_j.sum()), 3
+    x, y, h = _clouds(37, N, M, D)
+    ends_i, ends_j = np.cumsum(sizes_i), np.cumsum(sizes_j)
+    ri = np.stack([ends_i - sizes_i, ends_i], 1).astype(np.int32)
+    rj = np.stack([ends_j - sizes_j, ends_j], 1).astype(np.int32)
+    keep = rng.random((len(sizes_i), len(sizes_j))) < 0.5
+    keep[:, 3] = True                                     # every row block sees the big column block
+    rg = from_matrix(torch.from_numpy(ri).to(cuda), torch.from_numpy(rj).to(cuda), torch.from_numpy(keep).to(cuda))
+    tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    eps, blur = 0.02, 0.1
+    g = rng.standard_normal(N).astype(np.float32)
+    v = (rng.random(M) / M).astype(np.float32)
+    ref = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
+    refg = oracle_c.softmin_grad_x(eps, x, y, h, g, 2, ranges=tup)
+    refk = oracle_c.kconv("gaussian", x, y, v, blur, ranges=tup)
+    refkg = oracle_c.kconv_grad_x("gaussian", x, y, v, g, blur, ranges=tup)
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA, hip.FLAG_PREPACK, hip.FLAG_XDL16):
+        xt = _t(x, cuda).requires_grad_(True)
+        out = hip.softmin(eps, xt, _t(y, cuda), _t(h, cuda), p=2, ranges=rg, flags=flags)
+        assert np.abs(out.detach().cpu().numpy() - ref).max() < 1.2e-6 + 2e-6 * np.abs(ref).max(), flags
+        (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
+        assert relerr(gx.cpu().numpy(), refg) < 1e-5, flags
+        xt = _t(x, cuda).requires_grad_(True)
+        k = hip.kernel_conv("gaussian", xt, _t(y, cuda), _t(v, cuda), blur, ranges=rg, flags=flags)
+        assert relerr(k.detach().cpu().numpy(), refk) < 1e-4, flags
+        (gk,) = torch.autograd.grad(k, [xt], grad_outputs=_t(g, cuda))
+        assert relerr(gk.cpu().numpy(), refkg) < 1e-4, flags
+    # p = 1 / laplacian: the VALU operators go through the same table
+    out1 = hip.softmin(0.05, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=1, ranges=rg).cpu().numpy()
+    assert relerr(out1, oracle_c.softmin(0.05, x, y, h, 1, ranges=tup)) < 3e-6
+    kl = hip.kernel_conv("laplacian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg).cpu().numpy()
+    assert relerr(kl, oracle_c.kconv("laplacian", x, y, v, blur, ranges=tup)) < 3e-6
+    # no workspace at all (raw C-ABI call): the kernels fall back to one workgroup per row block
+    lib = hip.load_library()
+    xt, yt, ht = _t(x, cuda)[None].contiguous(), _t(y, cuda)[None].contiguous(), _t(h, cuda)[None].contiguous()
+    o = torch.empty((1, N), device=cuda)
+    rc = lib.glhip_softmin_fwd(xt.data_ptr(), yt.data_ptr(), ht.data_ptr(), o.data_ptr(), 1, N, M, D, eps, 2, hip.F32,
+                               *rg.c_args(), None, 0, 0, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and np.abs(o.cpu().numpy()[0] - ref).max() < 1.2e-6 + 2e-6 * np.abs(ref).max()
+
+
 KINDS = ["gaussian", "laplacian", "energy"]
 
 

@@ -1,5 +1,5 @@
 """Runs one BASELINE config end to end (for rocprofv3 --kernel-trace --stats and wall-clock checks).
-usage: python tools/run_config.py {multiscale|online|batched|gaussian} [reps]"""
+usage: python tools/run_config.py {multiscale|online|batched|gaussian|gaussian_ms} [reps]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,6 +26,11 @@ elif which == "gaussian":
     n = 1_000_000
     x, y = torch.rand(n, 3, generator=g).to(dev), torch.rand(n, 3, generator=g).to(dev)
     loss = SamplesLoss("gaussian", blur=0.05, backend="online")
+elif which == "gaussian_ms":
+    n = 1_000_000
+    x, y = torch.rand(n, 3, generator=g).to(dev), torch.rand(n, 3, generator=g).to(dev)
+    loss = SamplesLoss("gaussian", blur=float(os.environ.get("BLUR", 0.05)), truncate=float(os.environ.get("TRUNC", 5)),
+                       backend="multiscale", verbose=True)
 x.requires_grad_(True)
 for r in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
