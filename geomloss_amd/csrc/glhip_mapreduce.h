@@ -279,7 +279,7 @@ static inline void launch_mapreduce(const typename Op::Params& prm, const Ranges
     const int rows_per_block = kBlock * Op::kRows;
     unsigned chunk_grid = 0;
     const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, rows_per_block, cb, stream, chunk_grid) : rg;
-    const long row_blocks = n_ranges > 0 ? (long)chunk_grid : (long)B * ((N + rows_per_block - 1) / rows_per_block);
+    const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + rows_per_block - 1) / rows_per_block);
     const long per_split = (long)B * N * Op::kPartial * sizeof(float);
     const long fit = (workspace && per_split > 0) ? (long)(workspace_bytes / per_split) : 0;
     SplitInfo sp;
