@@ -101,3 +101,43 @@ def from_matrix(ranges_i, ranges_j, keep):
 
 def swap_axes(ranges):
     return ranges.t()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+#  device-side fast path (glhip_grid_cluster / glhip_block_ranges): what the drivers use on GPU clouds
+# ----------------------------------------------------------------------------------------------------------------------
+
+def native_clustering_applies(x, labels=None):
+    """The HIP clustering kernels take fp32 / bf16 clouds of dimension <= 3 on a GPU, clustered by voxels (no user labels)."""
+    from . import hip
+    return (labels is None and x.is_cuda and x.dim() == 2 and x.shape[1] <= 3 and x.shape[0] > 0
+            and x.dtype in (torch.float32, torch.bfloat16) and hip.library_available())
+
+
+def clusterize_device(a, x, scale, pre_div=1.0):
+    """``grid_cluster`` + ``cluster_ranges_centroids`` + ``sort_clusters`` in one call of ``glhip_grid_cluster``.
+
+    Returns ``(a_c, a_sorted, x_c, x_sorted, ranges, perm)`` with ``perm`` int64.  ``x_c`` are the centroids of ``x / pre_div``
+    (in the dtype of x), ``a_c`` the cluster weights (fp32).  The sorted cloud / weights stay differentiable with respect to
+    ``x`` / ``a`` when those require gradients (plain indexing); centroids and cluster weights never do, as in the reference."""
+    from . import hip
+    xd = x.detach().contiguous()
+    ad = None if a is None else a.detach().float().contiguous().view(-1)
+    need_graph = torch.is_grad_enabled() and (x.requires_grad or (a is not None and a.requires_grad))
+    perm32, xs, ws, ranges, cents, w_c = hip.grid_cluster_raw(xd, ad, scale, pre_div, gather=not need_graph)
+    perm = perm32.long()
+    if need_graph:
+        xs, ws = x[perm], (None if a is None else a[perm])
+    elif a is not None and a.dtype != torch.float32:
+        ws = ws.to(a.dtype)
+    return w_c, ws, cents.to(x.dtype), xs, ranges, perm
+
+
+def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+    """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``).  ``kind``: "dual_slack"
+    (f_i + g_j > C_ij - thr, sinkhorn_samples.py:512-514) or "within" (|c_i - c_j|^2 <= thr, kernel_samples.py:244-252)."""
+    from . import hip
+    code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
+    f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
+    return hip.block_ranges_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),
+                                ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p)

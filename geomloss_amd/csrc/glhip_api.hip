@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "glhip_error.h"
 #include "glhip_generic.h"
 #include "glhip_kconv_ops.h"
 #include "glhip_softmin_ops.h"
@@ -18,23 +19,11 @@
 
 using namespace glhip;
 
-namespace {
-
+namespace glhip {
 thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
 }
 
-int check_launch(const char* what) {
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GLHIP_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
-    return GLHIP_OK;
-}
+namespace {
 
 int check_common(const char* fn, const void* x, const void* y, const void* s, int B, int N, int M, int D,
                  int in_dtype, const int32_t* ri, const int32_t* si, const int32_t* rj, int n_ranges) {

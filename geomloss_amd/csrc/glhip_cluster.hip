@@ -1,0 +1,350 @@
+// glhip_cluster.hip — the cluster pyramid of the two-scale ("multiscale") backends, on the device:
+//   glhip_grid_cluster   voxel labels -> cluster-sorted cloud, per-cluster row ranges, weighted centroids, cluster weights
+//   glhip_block_ranges   cluster-cluster keep rule -> CSR lists of merged column intervals, both orientations
+// The reference does this with pykeops.torch.cluster.{grid_cluster, cluster_ranges_centroids, sort_clusters, from_matrix}
+// (torch ops; _legacy/sinkhorn_samples.py:453-530, _legacy/kernel_samples.py:214-256); geomloss_amd/cluster.py restates those
+// helpers with torch tensor ops (dozens of small launches, two host round trips each, and 1.2 s of lazily loaded torch code
+// objects on the first call).  Here: a handful of launches on the caller's stream, no host round trip inside the library,
+// deterministic results (fixed-order float64 sums, no atomics on floating-point data).
+#include <hipcub/hipcub.hpp>
+
+#include <climits>
+#include <cstdint>
+
+#include "glhip_common.h"
+#include "glhip_error.h"
+
+using namespace glhip;
+
+namespace {
+
+constexpr int kAxisBits = 21;                       // voxel coordinates (relative to the cloud's minimum) per axis
+constexpr int kAxisMax = (1 << kAxisBits) - 1;
+
+struct ClusterHead {        // first bytes of the workspace
+    int qmin[3];
+    int qmax[3];
+    int overflow;           // a voxel coordinate did not fit kAxisBits
+    int pad;
+};
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <typename T>
+__device__ __forceinline__ int voxel_of(const T* __restrict__ x, long idx, float pre_div, float voxel) {
+    // two IEEE divisions, as torch evaluates floor((x / blur) / size)
+    return (int)floorf((to_f32<T>(x[idx]) / pre_div) / voxel);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bounds_kernel(const T* __restrict__ x, int N, int D, float pre_div, float voxel, ClusterHead* head) {
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+        for (int d = 0; d < D; ++d) {
+            const int q = voxel_of<T>(x, i * D + d, pre_div, voxel);
+            lo[d] = min(lo[d], q);
+            hi[d] = max(hi[d], q);
+        }
+    }
+    for (int d = 0; d < D; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = min(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = max(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && lo[d] <= hi[d]) {
+            atomicMin(&head->qmin[d], lo[d]);
+            atomicMax(&head->qmax[d], hi[d]);
+        }
+    }
+}
+
+// key = voxel coordinates packed most-significant-axis first: sorting the keys sorts the voxels lexicographically, which is
+// the order of the labels pykeops' grid_cluster hands out
+template <typename T>
+__global__ void __launch_bounds__(256) keys_kernel(const T* __restrict__ x, int N, int D, float pre_div, float voxel, ClusterHead* head,
+                                                   uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    uint64_t key = 0;
+    for (int d = 0; d < D; ++d) {
+        const long q = (long)voxel_of<T>(x, i * D + d, pre_div, voxel) - head->qmin[d];
+        if (q > kAxisMax) head->overflow = 1;
+        key = (key << kAxisBits) | (uint64_t)(q & kAxisMax);
+    }
+    keys[i] = key;
+    idx[i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256) flags_kernel(const uint64_t* __restrict__ keys, int N, int32_t* __restrict__ flags) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// labels (inclusive scan of the flags) -> [start, end) of every cluster, and the cluster count
+__global__ void __launch_bounds__(256) ranges_kernel(const int32_t* __restrict__ incl, int N, int32_t* __restrict__ ranges, int32_t* n_clusters) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int c = incl[i] - 1;
+    if (i == 0 || incl[i - 1] != incl[i]) {
+        ranges[2 * c] = (int32_t)i;
+        if (c > 0) ranges[2 * (c - 1) + 1] = (int32_t)i;
+    }
+    if (i == N - 1) {
+        ranges[2 * c + 1] = N;
+        n_clusters[0] = c + 1;
+    }
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, off, 64);
+    hi = __shfl_xor(hi, off, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// one wavefront per cluster: weight and weighted centroid of (x / pre_div) in float64, in a fixed order
+template <typename T>
+__global__ void __launch_bounds__(256) centroids_kernel(const T* __restrict__ x, const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ n_clusters, int D,
+                                                        float pre_div, float* __restrict__ centroids, float* __restrict__ weights_c) {
+    const int lane = threadIdx.x & 63;
+    const int n_waves = gridDim.x * 4;
+    const int C = n_clusters[0];
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += n_waves) {
+        const int r0 = ranges[2 * c], r1 = ranges[2 * c + 1];
+        double sw = 0.0, sx[3] = {0.0, 0.0, 0.0};
+        for (int p = r0 + lane; p < r1; p += 64) {
+            const long j = perm[p];
+            const double wj = w ? (double)w[j] : 1.0;
+            sw += wj;
+            for (int d = 0; d < D; ++d) sx[d] += wj * (double)(to_f32<T>(x[j * D + d]) / pre_div);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sw += shfl_xor_f64(sw, off);
+            for (int d = 0; d < D; ++d) sx[d] += shfl_xor_f64(sx[d], off);
+        }
+        if (lane == 0) {
+            const double den = sw > 1e-9 ? sw : 1e-9;     // cluster_ranges_centroids' min_weight
+            for (int d = 0; d < D; ++d) centroids[(long)c * D + d] = (float)(sx[d] / den);
+            weights_c[c] = (float)sw;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gather_kernel(const T* __restrict__ x, const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                     int N, int D, T* __restrict__ x_sorted, float* __restrict__ w_sorted) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const long j = perm[p];
+    for (int d = 0; d < D; ++d) x_sorted[p * D + d] = x[j * D + d];
+    if (w_sorted) w_sorted[p] = w ? w[j] : 1.0f;
+}
+
+size_t sort_temp_bytes(int N) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    int32_t* v = nullptr;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, v, v, N, 0, 3 * kAxisBits, (hipStream_t)0) != hipSuccess || bytes == 0)
+        bytes = (size_t)N * 16 + (1 << 20);   // no device to ask (build box): a bound rocPRIM's merge/onesweep paths stay under
+    (void)hipGetLastError();
+    return bytes;
+}
+
+size_t scan_temp_bytes(int N) {
+    size_t bytes = 0;
+    int32_t* v = nullptr;
+    if (hipcub::DeviceScan::InclusiveSum(nullptr, bytes, v, v, N, (hipStream_t)0) != hipSuccess || bytes == 0)
+        bytes = (size_t)N * 4 + (1 << 20);
+    (void)hipGetLastError();
+    return bytes;
+}
+
+template <typename T>
+int grid_cluster_typed(const void* x_, const float* w, int N, int D, float pre_div, float voxel, int32_t* perm, void* x_sorted,
+                       float* w_sorted, int32_t* ranges, float* centroids, float* weights_c, int32_t* n_clusters, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
+    const T* x = static_cast<const T*>(x_);
+    char* ws = static_cast<char*>(workspace);
+    ClusterHead* head = reinterpret_cast<ClusterHead*>(ws);
+    size_t off = align256(sizeof(ClusterHead));
+    uint64_t* keys_in = reinterpret_cast<uint64_t*>(ws + off); off += align256((size_t)N * 8);
+    uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + off); off += align256((size_t)N * 8);
+    int32_t* idx_in = reinterpret_cast<int32_t*>(ws + off); off += align256((size_t)N * 4);
+    int32_t* flags = reinterpret_cast<int32_t*>(ws + off); off += align256((size_t)N * 4);
+    size_t temp_sort = sort_temp_bytes(N), temp_scan = scan_temp_bytes(N);
+    const size_t temp = temp_sort > temp_scan ? temp_sort : temp_scan;
+    if (off + temp > workspace_bytes)
+        return fail(GLHIP_EINVAL, "glhip_grid_cluster: workspace of %zu bytes, need %zu (glhip_cluster_workspace_bytes)", workspace_bytes, off + temp);
+    void* tmp = ws + off;
+
+    const int blocks = (N + 255) / 256;
+    (void)hipMemsetAsync(head->qmin, 0x7f, sizeof(head->qmin), st);     // INT-large
+    (void)hipMemsetAsync(head->qmax, 0x80, sizeof(head->qmax), st);     // INT-small
+    (void)hipMemsetAsync(&head->overflow, 0, 2 * sizeof(int), st);
+    hipLaunchKernelGGL((bounds_kernel<T>), dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, x, N, D, pre_div, voxel, head);
+    hipLaunchKernelGGL((keys_kernel<T>), dim3(blocks), dim3(256), 0, st, x, N, D, pre_div, voxel, head, keys_in, idx_in);
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, temp_sort, keys_in, keys_out, idx_in, perm, N, 0, D * kAxisBits, st) != hipSuccess)
+        return fail(GLHIP_ELAUNCH, "glhip_grid_cluster: radix sort failed: %s", hipGetErrorString(hipGetLastError()));
+    hipLaunchKernelGGL(flags_kernel, dim3(blocks), dim3(256), 0, st, keys_out, N, flags);
+    int32_t* incl = idx_in;   // the unsorted indices are no longer needed
+    if (hipcub::DeviceScan::InclusiveSum(tmp, temp_scan, flags, incl, N, st) != hipSuccess)
+        return fail(GLHIP_ELAUNCH, "glhip_grid_cluster: scan failed: %s", hipGetErrorString(hipGetLastError()));
+    hipLaunchKernelGGL(ranges_kernel, dim3(blocks), dim3(256), 0, st, incl, N, ranges, n_clusters);
+    hipLaunchKernelGGL((centroids_kernel<T>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, x, w, perm, ranges, n_clusters, D, pre_div,
+                       centroids, weights_c);
+    if (x_sorted)
+        hipLaunchKernelGGL((gather_kernel<T>), dim3(blocks), dim3(256), 0, st, x, w, perm, N, D, static_cast<T*>(x_sorted), w_sorted);
+    // the overflow flag travels with the cluster count: n_clusters[1]
+    (void)hipMemcpyAsync(n_clusters + 1, &head->overflow, sizeof(int), hipMemcpyDeviceToDevice, st);
+    return check_launch("glhip_grid_cluster");
+}
+
+// ---- keep rule -> merged column intervals ------------------------------------------------------------------------------
+
+struct KeepRule {
+    int kind;              // GLHIP_KEEP_DUAL_SLACK | GLHIP_KEEP_WITHIN
+    const float* rows;     // (Cr, D) centroids of the row clusters
+    const float* cols;     // (Cc, D)
+    const float* f;        // (Cr) dual values of the rows   (dual slack only)
+    const float* g;        // (Cc)
+    int D, p;
+    float thr;
+};
+
+__device__ __forceinline__ bool keep_pair(const KeepRule& k, int i, int j) {
+    float d2 = 0.f;
+    for (int d = 0; d < k.D; ++d) {
+        const float t = k.rows[(long)i * k.D + d] - k.cols[(long)j * k.D + d];
+        d2 = __builtin_fmaf(t, t, d2);
+    }
+    if (k.kind == GLHIP_KEEP_WITHIN) return d2 <= k.thr;                       // kernel_samples.py:244-252
+    const float C = (k.p == 2) ? 0.5f * d2 : sqrtf(fmaxf(d2, 1e-8f));          // cost_routines, sinkhorn_samples.py:26-29
+    return k.f[i] + k.g[j] > C - k.thr;                                        // sinkhorn_samples.py:512-514
+}
+
+// One wavefront per row cluster.  A "run" is a maximal sequence of kept column clusters that are adjacent in memory
+// (range end == next range start): it becomes ONE column interval (same pair set as one interval per cluster, longer
+// tiles for the kernels).  Every run has one start and one stop and they alternate along the row, so the k-th start and the
+// k-th stop belong to the same run: ranks are plain prefix counts.
+// FILL = false: counts[i] = number of runs.  FILL = true: writes the runs at offset slices[i-1] of `red`.
+template <bool FILL>
+__global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_cols,
+                                                   int32_t* __restrict__ counts, const int32_t* __restrict__ slices,
+                                                   int32_t* __restrict__ red, int capacity, int32_t* overflow) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= Cr) return;
+    const int base = FILL ? (i == 0 ? 0 : slices[i - 1]) : 0;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int n_starts = 0, n_stops = 0;
+    int prev_keep = 0, prev_end = -1;     // column c0 - 1 (wave-uniform)
+    for (int c0 = 0; c0 < Cc; c0 += 64) {
+        const int c = c0 + lane;
+        const int k = (c < Cc && keep_pair(rule, i, c)) ? 1 : 0;
+        const int cs = c < Cc ? ranges_cols[2 * c] : -2, ce = c < Cc ? ranges_cols[2 * c + 1] : -3;
+        int kl = __shfl_up(k, 1, 64), el = __shfl_up(ce, 1, 64);
+        if (lane == 0) { kl = prev_keep; el = prev_end; }
+        int kr = __shfl_down(k, 1, 64), sr = __shfl_down(cs, 1, 64);
+        if (lane == 63) {   // the right neighbour lives in the next chunk
+            kr = (c + 1 < Cc && keep_pair(rule, i, c + 1)) ? 1 : 0;
+            sr = c + 1 < Cc ? ranges_cols[2 * (c + 1)] : -4;
+        }
+        const bool start = k && !(kl && el == cs);
+        const bool stop = k && !(kr && sr == ce);
+        const unsigned long long ms = __ballot(start), me = __ballot(stop);
+        if (FILL) {
+            if (start) {
+                const int slot = base + n_starts + __popcll(ms & below);
+                if (slot < capacity) red[2 * slot] = cs; else *overflow = 1;
+            }
+            if (stop) {
+                const int slot = base + n_stops + __popcll(me & below);
+                if (slot < capacity) red[2 * slot + 1] = ce; else *overflow = 1;
+            }
+        }
+        n_starts += __popcll(ms);
+        n_stops += __popcll(me);
+        prev_keep = __shfl(k, 63, 64);
+        prev_end = __shfl(ce, 63, 64);
+    }
+    if (!FILL && lane == 0) counts[i] = n_starts;
+}
+
+// inclusive scan of `counts` (n <= a few 1e5) by a single workgroup -> CSR end offsets
+__global__ void __launch_bounds__(1024) slices_kernel(const int32_t* __restrict__ counts, int n, int32_t* __restrict__ slices) {
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + tid;
+        scan[tid] = k < n ? counts[k] : 0;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = (tid >= off) ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (k < n) slices[k] = carry + scan[tid];
+        __syncthreads();
+        if (tid == 1023) carry += scan[1023];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t glhip_cluster_workspace_bytes(int N, int D) {
+    if (N <= 0 || D < 1 || D > 3) return 0;
+    const size_t ts = sort_temp_bytes(N), tc = scan_temp_bytes(N);
+    return align256(sizeof(ClusterHead)) + 2 * align256((size_t)N * 8) + 2 * align256((size_t)N * 4) + align256(ts > tc ? ts : tc);
+}
+
+int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in_dtype, float pre_div, float voxel, int32_t* perm,
+                       void* x_sorted, float* w_sorted, int32_t* ranges, float* centroids, float* weights_c, int32_t* n_clusters,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || D < 1 || D > 3) return fail(N < 0 ? GLHIP_EINVAL : GLHIP_EUNSUPPORTED, "glhip_grid_cluster: bad sizes N=%d D=%d (D <= 3)", N, D);
+    if (in_dtype != GLHIP_F32 && in_dtype != GLHIP_BF16) return fail(GLHIP_EINVAL, "glhip_grid_cluster: bad in_dtype %d", in_dtype);
+    if (!(voxel > 0.f) || !(pre_div > 0.f)) return fail(GLHIP_EINVAL, "glhip_grid_cluster: voxel and pre_div must be > 0");
+    if (!n_clusters) return fail(GLHIP_EINVAL, "glhip_grid_cluster: NULL n_clusters");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        (void)hipMemsetAsync(n_clusters, 0, 2 * sizeof(int32_t), st);
+        return GLHIP_OK;
+    }
+    if (!x || !perm || !ranges || !centroids || !weights_c || !workspace)
+        return fail(GLHIP_EINVAL, "glhip_grid_cluster: NULL pointer");
+    return in_dtype == GLHIP_F32
+               ? grid_cluster_typed<float>(x, weights, N, D, pre_div, voxel, perm, x_sorted, w_sorted, ranges, centroids, weights_c, n_clusters, workspace, workspace_bytes, st)
+               : grid_cluster_typed<bf16_t>(x, weights, N, D, pre_div, voxel, perm, x_sorted, w_sorted, ranges, centroids, weights_c, n_clusters, workspace, workspace_bytes, st);
+}
+
+int glhip_block_ranges(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D, int p,
+                       float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, int32_t* slices_rows, int32_t* red_cols,
+                       int32_t* slices_cols, int32_t* red_rows, int capacity, int32_t* status, void* stream) {
+    if (kind != GLHIP_KEEP_DUAL_SLACK && kind != GLHIP_KEEP_WITHIN) return fail(GLHIP_EINVAL, "glhip_block_ranges: bad kind %d", kind);
+    if (Cr < 0 || Cc < 0 || D < 1 || capacity < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges: bad sizes");
+    if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_block_ranges: p must be 1 or 2");
+    if (Cr == 0 || Cc == 0) return GLHIP_OK;
+    if (!rows || !cols || !ranges_rows || !ranges_cols || !slices_rows || !red_cols || !slices_cols || !red_rows || !status ||
+        (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
+        return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
+    const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
+    // the CSR offsets double as the count buffers of the first pass
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0, status);
+    hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_rows, Cr, slices_rows);
+    hipLaunchKernelGGL((runs_kernel<true>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, nullptr, slices_rows, red_cols, capacity, status);
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0, status);
+    hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
+    hipLaunchKernelGGL((runs_kernel<true>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, nullptr, slices_cols, red_rows, capacity, status);
+    return check_launch("glhip_block_ranges");
+}
+
+}  // extern "C"

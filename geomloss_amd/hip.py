@@ -45,7 +45,12 @@ SIGNATURES = {
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
     "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_lse_lines_bwd": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
+    "glhip_cluster_workspace_bytes": (_c_size, [_c_int, _c_int]),
+    "glhip_grid_cluster": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, _c_float] + [_vp] * 7 + [_vp, _c_size, _vp]),
+    "glhip_block_ranges": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 6
+                           + [_c_int, _vp, _vp]),
 }
+KEEP_DUAL_SLACK, KEEP_WITHIN = 0, 1
 
 _lib = None
 _warned = {"f64": False}
@@ -271,6 +276,57 @@ def softmin_dense_fwd_raw(C, h, eps):
         rc = lib.glhip_softmin_dense_fwd(C.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, float(eps), _stream(C))
     _check(rc, lib)
     return out
+
+
+def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True):
+    """Voxel clustering on the device (``glhip_grid_cluster``).  x (N,D) fp32|bf16 contiguous CUDA, weights (N,) fp32 or None.
+
+    Returns ``(perm, x_sorted, w_sorted, ranges, centroids, weights_c)``: ``perm`` (N,) int32; ``x_sorted`` / ``w_sorted`` the
+    cloud in cluster order (None without ``gather``); ``ranges`` (C,2) int32, ``centroids`` (C,D) fp32 of ``x / pre_div``,
+    ``weights_c`` (C,) fp32.  One host read-back (the cluster count) sizes the outputs."""
+    lib = load_library()
+    N, D = x.shape
+    dev = x.device
+    with torch.cuda.device(dev):
+        perm = torch.empty(N, dtype=torch.int32, device=dev)
+        x_sorted = torch.empty_like(x) if gather else None
+        w_sorted = torch.empty(N, dtype=torch.float32, device=dev) if gather else None
+        ranges = torch.empty((N, 2), dtype=torch.int32, device=dev)
+        cents = torch.empty((N, D), dtype=torch.float32, device=dev)
+        w_c = torch.empty(N, dtype=torch.float32, device=dev)
+        count = torch.empty(2, dtype=torch.int32, device=dev)
+        nbytes = int(lib.glhip_cluster_workspace_bytes(N, D))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        rc = lib.glhip_grid_cluster(x.data_ptr(), ptr(weights), N, D, _dtype_code(x), float(pre_div), float(voxel), perm.data_ptr(),
+                                    ptr(x_sorted), ptr(w_sorted), ranges.data_ptr(), cents.data_ptr(), w_c.data_ptr(),
+                                    count.data_ptr(), ws.data_ptr(), nbytes, _stream(x))
+    _check(rc, lib)
+    C, overflow = (int(v) for v in count.tolist())      # the one host round trip
+    if overflow:
+        raise ValueError("geomloss_amd: the voxel grid has more than 2^21 cells along an axis; use a larger cluster_scale.")
+    return perm, x_sorted, w_sorted, ranges[:C], cents[:C], w_c[:C]
+
+
+def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+    """Keep rule on cluster pairs -> :class:`BlockRanges` (``glhip_block_ranges``), no host round trip."""
+    lib = load_library()
+    Cr, D = rows.shape
+    Cc = cols.shape[0]
+    dev = rows.device
+    cap = max(Cr * ((Cc + 1) // 2), Cc * ((Cr + 1) // 2), 1)
+    with torch.cuda.device(dev):
+        slices_r = torch.empty(Cr, dtype=torch.int32, device=dev)
+        slices_c = torch.empty(Cc, dtype=torch.int32, device=dev)
+        red_c = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        red_r = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        rc = lib.glhip_block_ranges(int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, Cc, D, int(p), float(thr),
+                                    ranges_rows.data_ptr(), ranges_cols.data_ptr(), slices_r.data_ptr(), red_c.data_ptr(),
+                                    slices_c.data_ptr(), red_r.data_ptr(), cap, status.data_ptr(), _stream(rows))
+    _check(rc, lib)
+    return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
 
 # ----------------------------------------------------------------------------------------------

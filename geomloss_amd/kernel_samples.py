@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import hip
-from .cluster import cluster_ranges_centroids, from_matrix, grid_cluster, sort_clusters
+from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, from_matrix, grid_cluster,
+                      native_clustering_applies, sort_clusters)
 from .utils import distances, scal, squared_distances
 
 
@@ -151,6 +152,21 @@ def kernel_multiscale(
         diameter = max_diameter(x_.view(-1, D), y_.view(-1, D)) if diameter is None else diameter / blur
         cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
     cell_diameter = cluster_scale * np.sqrt(D)
+
+    if native_clustering_applies(x) and native_clustering_applies(y) and α.dim() == 1:
+        # device path: glhip_grid_cluster clusters x / blur itself (pre_div), glhip_block_ranges applies the geometric rule
+        _, α, x_c, x, ranges_x, _ = clusterize_device(α, x, cluster_scale, pre_div=blur)
+        _, β, y_c, y, ranges_y, _ = clusterize_device(β, y, cluster_scale, pre_div=blur)
+        if verbose:
+            print("{}x{} clusters, computed at scale = {:2.3f}".format(len(x_c), len(y_c), cluster_scale))
+        reach2 = (truncate + cell_diameter) ** 2
+        ranges_xx = block_ranges_device("within", x_c, x_c, None, None, ranges_x, ranges_x, reach2)
+        ranges_yy = block_ranges_device("within", y_c, y_c, None, None, ranges_y, ranges_y, reach2)
+        ranges_xy = block_ranges_device("within", x_c, y_c, None, None, ranges_x, ranges_y, reach2)
+        return kernel_loss(
+            α, x, β, y, blur=blur, kernel=kernel, name=name, potentials=potentials, use_keops=True,
+            ranges_xx=ranges_xx, ranges_yy=ranges_yy, ranges_xy=ranges_xy,
+        )
 
     x_lab = grid_cluster(x_, cluster_scale)
     y_lab = grid_cluster(y_, cluster_scale)

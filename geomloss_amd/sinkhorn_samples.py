@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from . import hip
-from .cluster import cluster_ranges_centroids, from_matrix, grid_cluster, swap_axes
+from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, from_matrix, grid_cluster,
+                      native_clustering_applies, swap_axes)
 from .sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
@@ -28,10 +29,16 @@ from .utils import distances, squared_distances
 #                          backend == "tensorized"
 # ==============================================================================
 
-cost_routines = {
-    1: (lambda x, y: distances(x, y)),
-    2: (lambda x, y: squared_distances(x, y) / 2),
-}
+def _cost_p1(x, y):
+    return distances(x, y)
+
+
+def _cost_p2(x, y):
+    return squared_distances(x, y) / 2
+
+
+_cost_p1.glhip_exponent, _cost_p2.glhip_exponent = 1, 2     # lets kernel_truncation evaluate the keep rule on the device
+cost_routines = {1: _cost_p1, 2: _cost_p2}
 
 
 def softmin_tensorized(eps, C_xy, h_y):
@@ -265,6 +272,9 @@ def clusterize(a, x, scale=None, labels=None):
     """
     if labels is None and scale is None:
         return [a], [x], []
+    if native_clustering_applies(x, labels):     # one C-ABI call instead of ~25 torch launches and two host round trips
+        a_c, a_s, x_c, x_s, ranges_x, perm = clusterize_device(a, x, scale)
+        return [a_c, a_s], [x_c, x_s], [ranges_x], perm
     x_lab = grid_cluster(x, scale) if labels is None else labels
     _, perm = torch.sort(x_lab.view(-1), stable=True)
     ranges_x, x_c, a_c = cluster_ranges_centroids(x, x_lab, weights=a, perm=perm)
@@ -279,6 +289,10 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     y, xd, _, _, _ = C_yx
     x_, yd_, ranges_x_, ranges_y_, _ = C_xy_
     y_, xd_, _, _, _ = C_yx_
+    native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
+    if native_p is not None and not verbose and native_clustering_applies(x):
+        ranges_xy_ = block_ranges_device("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps, p=native_p)
+        return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
     with torch.no_grad():
         C = cost(x, y)
         keep = f_ba.view(-1, 1) + g_ab.view(1, -1) > C - truncate * eps

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 105 /* 0.1.5 */
+#define GLHIP_VERSION 106 /* 0.1.6 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -211,6 +211,45 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
 int glhip_softmin_dense_fwd(const float* C, const float* h, float* out,
                             int B, int N, int M, float eps, void* stream);
 
+/*
+ * The cluster pyramid of the two-scale ("multiscale") backends, on the device.
+ *
+ * glhip_grid_cluster — voxel clustering of a weighted cloud.  Replaces the chain
+ *   pykeops.torch.cluster.grid_cluster -> cluster_ranges_centroids -> sort_clusters
+ * of `clusterize`, sinkhorn_samples.py:453-490, and kernel_samples.py:214-236: points are binned in cubic voxels of edge
+ * `voxel` (bin of a coordinate c: floor((c / pre_div) / voxel); kernel_multiscale clusters x / blur, sinkhorn passes 1),
+ * clusters are numbered in lexicographic voxel order (first axis most significant), and the cloud is sorted by cluster with
+ * a STABLE sort, so that cluster k is the contiguous row range [ranges[2k], ranges[2k+1]) of the sorted cloud.
+ *   x (N,D) fp32|bf16, D <= 3;  weights (N) fp32 or NULL (all ones)
+ *   perm (N) int32 out: sorted row p is input row perm[p];   x_sorted (N,D) / w_sorted (N) out, may be NULL
+ *   ranges (N,2) int32, centroids (N,D) fp32 (weighted means of x / pre_div), weights_c (N) fp32: the first C rows are
+ *   written, C <= N = the number of non-empty voxels;  n_clusters (2) int32 out: {C, overflow} — overflow != 0 means a
+ *   voxel coordinate exceeded 2^21 bins along an axis (result invalid; use a larger voxel).
+ * Sums are accumulated in float64 in a fixed order: the same inputs give the same centroids bit for bit.  Nothing comes
+ * back to the host: read n_clusters when the sizes are needed.  workspace: glhip_cluster_workspace_bytes(N, D).
+ *
+ * glhip_block_ranges — a keep rule on pairs of clusters -> block-sparse reduction ranges for both orientations.
+ * Replaces `keep = ...` + pykeops.torch.cluster.from_matrix at sinkhorn_samples.py:512-530 (GLHIP_KEEP_DUAL_SLACK:
+ * keep (i,j) iff f_i + g_j > C(rows_i, cols_j) - thr, C the cost of exponent p on the centroids, thr = truncate * eps) and
+ * kernel_samples.py:244-256 (GLHIP_KEEP_WITHIN: keep iff |rows_i - cols_j|^2 <= thr, thr = (truncate + cell diameter)^2).
+ *   rows (Cr,D), cols (Cc,D) fp32 centroids;  f (Cr), g (Cc) dual values (dual slack only);
+ *   ranges_rows (Cr,2), ranges_cols (Cc,2): row ranges of the clusters in their sorted clouds;
+ *   out: slices_rows (Cr) + red_cols (capacity,2) = the (slices_i, redranges_j) of a reduction over the columns of every
+ *        row cluster, slices_cols (Cc) + red_rows (capacity,2) = the same for the transposed reduction.  Kept column
+ *        clusters that are adjacent in memory are merged into one interval (same pair set, fewer and longer tiles).
+ *   capacity: intervals each `red_*` array can hold; Cr * ((Cc + 1) / 2) (resp. Cc * ((Cr + 1) / 2)) always suffices.
+ *   status (1) int32 out: != 0 if capacity was exceeded.
+ */
+#define GLHIP_KEEP_DUAL_SLACK 0
+#define GLHIP_KEEP_WITHIN 1
+size_t glhip_cluster_workspace_bytes(int N, int D);
+int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in_dtype, float pre_div, float voxel,
+                       int32_t* perm, void* x_sorted, float* w_sorted, int32_t* ranges, float* centroids,
+                       float* weights_c, int32_t* n_clusters, void* workspace, size_t workspace_bytes, void* stream);
+int glhip_block_ranges(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
+                       int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
+                       int32_t* slices_rows, int32_t* red_cols, int32_t* slices_cols, int32_t* red_rows, int capacity,
+                       int32_t* status, void* stream);
 #ifdef __cplusplus
 }
 #endif
