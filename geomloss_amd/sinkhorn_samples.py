@@ -134,9 +134,12 @@ class _HipSoftmin:
     def _iter4_plan(self, C_xy, a_log, b_log, debias, create):
         """The hip.Iter4Plan of the loop being run, (re)built when the inputs change; None when the one-launch-per-iteration
         path does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the GPU
-        on its own (those run faster as separate launches with pre-packed columns)."""
+        on its own (those run faster as separate launches with pre-packed columns).  The coarse level of the multiscale
+        backend (dense, ~2e3 clusters with their own weights) qualifies: its 7 x 4 soft-mins become 7 launches."""
         x, y = C_xy[0], C_xy[1]
-        if self.multiscale or self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations:
+        if self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations:
+            return None
+        if self.multiscale and C_xy[4] is not None:     # truncated fine level: block-sparse launches
             return None
         B = 1 if x.dim() == 2 else x.shape[0]
         if float(B) * x.shape[-2] * y.shape[-2] >= 5e8:
