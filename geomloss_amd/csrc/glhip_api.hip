@@ -479,6 +479,16 @@ void launch_gauss_mfma(const ConvParams<T>& prm, float blur, const Ranges& rg, i
     else launch_wsum<WS_GAUSS_FWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, false>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
 }
 
+// gaussian product + its row gradient in one pass (WS_GAUSS_FWDGRAD)
+template <int D, typename T>
+void launch_gauss_fwdgrad(const ConvParams<T>& prm, float blur, const Ranges& rg, int n_ranges, int B, int N, int M,
+                          const Scratch& sc, hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.v; w.fwd = nullptr; w.g = nullptr; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = kLog2e / (blur * blur); w.out_scale = 1.f; w.gscale = -1.0f / (blur * blur); w.tscale = prm.t;
+    launch_wsum<WS_GAUSS_FWDGRAD, D, T, GaussFwdGradMerge<D, T>>(w, prm, rg, n_ranges, B, N, M, sc, false, st);
+}
+
 template <bool BWD, typename T>
 int conv_typed(int kind, const void* x, const void* y, const float* v, float* out, const float* g, float* gx,
                int B, int N, int M, int D, float blur, const Ranges& rg, int n_ranges, const Scratch& sc,
@@ -763,6 +773,36 @@ int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float*
              ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
              : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st);
     return rc ? rc : check_launch("glhip_kernel_conv_bwd_x");
+}
+
+int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const float* v, float* out, float* grad_unit,
+                               int B, int N, int M, int D, float blur, int in_dtype, const int32_t* ranges_i,
+                               const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                               size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_kernel_conv_fwd_grad", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (kind != GLHIP_GAUSSIAN || D > 3 || (flags & GLHIP_FLAG_NO_MFMA))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: only the gaussian kernel, D <= 3, on the matrix-core kernels "
+                                        "(got kind %d, D %d, flags %d): call glhip_kernel_conv_fwd + glhip_kernel_conv_bwd_x", kind, D, flags);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    if (!out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: NULL out / grad_unit");
+    if (!(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        ConvParams<T> prm;
+        prm.x = static_cast<const T*>(x); prm.y = static_cast<const T*>(y); prm.v = v; prm.out = out; prm.g = nullptr; prm.gx = grad_unit;
+        prm.t = std::sqrt(0.5f * kLog2e) / blur;
+        prm.gscale = -1.0f / (prm.t * blur * blur);
+        prm.clamp2 = 0.f;
+        if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        else launch_gauss_fwdgrad<3, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+    };
+    if (in_dtype == GLHIP_F32) run(float{}); else run(bf16_t{});
+    return check_launch("glhip_kernel_conv_fwd_grad");
 }
 
 int glhip_softmin_dense_fwd(const float* C, const float* h, float* out, int B, int N, int M, float eps,

@@ -163,4 +163,27 @@ struct ConvOp {
     }
 };
 
+// merge of the column splits of WS_GAUSS_FWDGRAD (glhip_wsum_mfma.h): partial = { t (xt S0 - S1)_d , S0 }
+template <int D_, typename T>
+struct GaussFwdGradMerge {
+    static constexpr int kDim = D_;
+    static constexpr int kRows = 1;
+    static constexpr int kPartial = D_ + 1;
+    using Params = ConvParams<T>;
+    static __device__ __forceinline__ void load_centre(const Params&, int, int, int, float (&)[D_]) {}
+    static __device__ __forceinline__ void merge_row(const Params& p, int b, int N, int i, const float (&)[D_],
+                                                     const float* part, int ns, long stride) {
+        float acc[kPartial];
+#pragma unroll
+        for (int d = 0; d < kPartial; ++d) acc[d] = 0.f;
+        for (int k = 0; k < ns; ++k) {
+#pragma unroll
+            for (int d = 0; d < kPartial; ++d) acc[d] += part[k * stride + d];
+        }
+        p.out[(long)b * N + i] = acc[D_];
+#pragma unroll
+        for (int d = 0; d < D_; ++d) p.gx[((long)b * N + i) * D_ + d] = p.gscale * acc[d];
+    }
+};
+
 }  // namespace glhip

@@ -6,6 +6,9 @@
 //   WS_GAUSS_FWD   : gaussian kernel product.  C_i = r_i = -s/2 |xt_i|^2, H_j = -s/2 |yt_j|^2, s = log2(e)/blur^2,
 //                    weights k_ij <= 1;  q_j = v_j.
 //   WS_GAUSS_BWD   : its gradient in x.  q_j = (v_j yt_j, v_j);  grad = -(g_i/blur^2) (xt_i S0 - S1).
+//   WS_GAUSS_FWDGRAD : product AND its row gradient in one pass — S0 is the product itself: out_i = S0,
+//                    dout_i/dx_i = -(1/blur^2) (xt_i S0 - S1).  Used by the autograd forward when x requires gradients, so that
+//                    the backward pass of a kernel norm is elementwise (fwd + bwd of the gaussian MMD: 3 + 2 reductions -> 3).
 // Exponents are <= 0 by construction, so there is no running max.  Same wave / LDS layout and the same
 // bf16 x 3 exponent MFMA as the forward soft-min (glhip_softmin_xdl.h): lane l holds D rows 4*(l/16)+r and
 // column l%16 of each 16-column group.
@@ -22,7 +25,7 @@
 
 namespace glhip {
 
-enum WsumMode { WS_SOFTMIN_BWD = 0, WS_GAUSS_FWD = 1, WS_GAUSS_BWD = 2 };
+enum WsumMode { WS_SOFTMIN_BWD = 0, WS_GAUSS_FWD = 1, WS_GAUSS_BWD = 2, WS_GAUSS_FWDGRAD = 3 };
 
 template <typename T>
 struct WsumParams {
@@ -54,7 +57,7 @@ template <int MODE, int D> struct WsumShape {
     static constexpr int kNQ = (MODE == WS_SOFTMIN_BWD) ? D : (MODE == WS_GAUSS_FWD ? 1 : D + 1);   // LDS q vectors
     static constexpr int kNA = (MODE == WS_GAUSS_FWD) ? 1 : D + 1;                                  // accumulators
     // floats per row in the split workspace = kPartial of the VALU operator whose merge_row finishes the job
-    static constexpr int kPart = (MODE == WS_SOFTMIN_BWD) ? D + 1 : (MODE == WS_GAUSS_FWD ? 1 : D);
+    static constexpr int kPart = (MODE == WS_SOFTMIN_BWD || MODE == WS_GAUSS_FWDGRAD) ? D + 1 : (MODE == WS_GAUSS_FWD ? 1 : D);
 };
 
 template <int MODE, int D, typename T, bool SPARSE>
@@ -228,6 +231,16 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                             } else if (MODE == WS_GAUSS_FWD) {
                                 if (ns == 1) prm.out[(long)b * N + i] = a_[0];
                                 else part[0] = a_[0];
+                            } else if (MODE == WS_GAUSS_FWDGRAD) {
+                                if (ns == 1) {
+                                    prm.out[(long)b * N + i] = a_[D];
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = prm.gscale * (xt[d] * a_[D] - a_[d]);
+                                } else {
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) part[d] = prm.tscale * (xt[d] * a_[D] - a_[d]);
+                                    part[D] = a_[D];
+                                }
                             } else {
                                 // sum_j v k (x - y) = xt S0 - S1
                                 if (ns == 1) {

@@ -42,6 +42,8 @@ SIGNATURES = {
                               + _RANGES + _TAIL),
     "glhip_kernel_conv_bwd_x": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                          _c_int] + _RANGES + _TAIL),
+    "glhip_kernel_conv_fwd_grad": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
+                                            _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
     "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_lse_lines_bwd": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
@@ -266,6 +268,22 @@ def kernel_conv_bwd_x_raw(kind, x, y, v, g, blur, ranges=None, flags=0):
                                          *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
     _check(rc, lib)
     return gx
+
+
+def kernel_conv_fwd_grad_raw(kind, x, y, v, blur, ranges=None, flags=0):
+    """out = K v and d out_i / d x_i in one pass (``glhip_kernel_conv_fwd_grad``; gaussian, D <= 3) -> (B,N), (B,N,D)."""
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    gu = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
+        rc = lib.glhip_kernel_conv_fwd_grad(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), out.data_ptr(), gu.data_ptr(),
+                                            B, N, M, D, float(blur), _dtype_code(x), *_range_args(ranges, B), *ws_args,
+                                            int(flags), _stream(x))
+    _check(rc, lib)
+    return out, gu
 
 
 def softmin_dense_fwd_raw(C, h, eps):
@@ -520,7 +538,15 @@ class _KernelConv(torch.autograd.Function):
         xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        out = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, flags)
+        # When x requires gradients, the gaussian product and its row gradient come out of ONE reduction: the mass
+        # accumulator of the gradient kernel is the product itself.  The backward pass is then elementwise.
+        fused = (_fuse_kernel_grad and kind == GAUSSIAN and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
+                 and not (flags & FLAG_NO_MFMA))
+        if fused:
+            out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
+        else:
+            out, unit = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, flags), None
+        ctx.unit = unit
         ctx.save_for_backward(xb, yb, vb)
         ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
         return out if batched else out.view(-1)
@@ -533,12 +559,24 @@ class _KernelConv(torch.autograd.Function):
         rt = None if ranges is None else ranges.t()
         gx = gy = gv = None
         if ctx.needs_input_grad[1]:
-            gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges, flags).reshape(xs).to(xdt)
+            if ctx.unit is not None:
+                gx = (g.unsqueeze(-1) * ctx.unit).reshape(xs).to(xdt)
+            else:
+                gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges, flags).reshape(xs).to(xdt)
         if ctx.needs_input_grad[2]:
             gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt, flags).reshape(ys).to(ydt)
         if ctx.needs_input_grad[3]:
             gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt, flags).reshape(vs).to(vdt)
         return None, gx, gy, gv, None, None, None
+
+
+# product + row gradient in one pass when x requires gradients (GEOMLOSS_HIP_FUSE_GRAD=0: always two reductions)
+_fuse_kernel_grad = os.environ.get("GEOMLOSS_HIP_FUSE_GRAD", "1") != "0"
+
+
+def set_kernel_grad_fusion(enabled):
+    global _fuse_kernel_grad
+    _fuse_kernel_grad = bool(enabled)
 
 
 def kernel_conv(kind, x, y, v, blur=0.05, ranges=None, flags=0):

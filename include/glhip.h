@@ -212,6 +212,19 @@ int glhip_softmin_dense_fwd(const float* C, const float* h, float* out,
                             int B, int N, int M, float eps, void* stream);
 
 /*
+ * Kernel product AND its gradient with respect to the row points in ONE pass (gaussian kernel, D <= 3):
+ *   out[b,i]         = sum_j k(x_i, y_j) v_j                      (what glhip_kernel_conv_fwd returns)
+ *   grad_unit[b,i,:] = d out[b,i] / d x[b,i,:] = -(1/blur^2) sum_j v_j k(x_i, y_j) (x_i - y_j)
+ * i.e. glhip_kernel_conv_bwd_x for grad_out = 1 — the mass accumulator of that reduction IS the product.  The autograd
+ * forward of the kernel norms calls this when x requires gradients; the backward pass is then grad_out[b,i] * grad_unit[b,i,:],
+ * an elementwise product (kernel_samples.py:92-146 with gradients: 3 + 2 reductions become 3).
+ * Other kernels / D > 3 / GLHIP_FLAG_NO_MFMA: GLHIP_EUNSUPPORTED (call the two entry points above).
+ */
+int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const float* v, float* out, float* grad_unit,
+                               int B, int N, int M, int D, float blur, int in_dtype,
+                               const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                               void* workspace, size_t workspace_bytes, int flags, void* stream);
+/*
  * The cluster pyramid of the two-scale ("multiscale") backends, on the device.
  *
  * glhip_grid_cluster — voxel clustering of a weighted cloud.  Replaces the chain
