@@ -579,6 +579,10 @@ def set_kernel_grad_fusion(enabled):
     _fuse_kernel_grad = bool(enabled)
 
 
+def kernel_grad_fusion():
+    return _fuse_kernel_grad
+
+
 def kernel_conv(kind, x, y, v, blur=0.05, ranges=None, flags=0):
     """Kernel-matrix x vector product on the GPU; ``kind`` is a name or a GLHIP_* code."""
     kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)

@@ -63,14 +63,14 @@ kernel_routines = {
 class _LazyKernel:
     """Stand-in for the KeOps LazyTensor the reference builds at ``:62-82``: supports ``K @ v`` and ``K.t()``."""
 
-    def __init__(self, name, x, y, blur, ranges=None):
-        self.name, self.x, self.y, self.blur, self.ranges = name, x, y, blur, ranges
+    def __init__(self, name, x, y, blur, ranges=None, flags=0):
+        self.name, self.x, self.y, self.blur, self.ranges, self.flags = name, x, y, blur, ranges, flags
 
     def __matmul__(self, v):  # v: (..., M, 1)
-        return hip.kernel_conv(self.name, self.x, self.y, v.squeeze(-1), self.blur, self.ranges).unsqueeze(-1)
+        return hip.kernel_conv(self.name, self.x, self.y, v.squeeze(-1), self.blur, self.ranges, flags=self.flags).unsqueeze(-1)
 
     def t(self):
-        return _LazyKernel(self.name, self.y, self.x, self.blur, None if self.ranges is None else self.ranges.t())
+        return _LazyKernel(self.name, self.y, self.x, self.blur, None if self.ranges is None else self.ranges.t(), self.flags)
 
 
 def _matvec(K, v):
@@ -89,7 +89,15 @@ def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
             )
         if name not in kernel_routines:
             raise KeyError(name)
-        build = lambda u, w, r: _LazyKernel(name, u, w, blur, r)  # noqa: E731
+        # A kernel norm is a difference of three large terms (two samples of one law: 1e-5 left of 1e-3).  When gradients are on,
+        # the products whose first cloud requires them run on the product-and-gradient kernel (hip._KernelConv); the other
+        # products of the same loss are then sent to the kernel of the same family (16x16x32 MFMA tiling, identical exponent
+        # arithmetic) so that the per-term rounding bias stays common to the three terms and cancels as before.
+        flags = 0
+        if (name == "gaussian" and x.shape[-1] <= 3 and torch.is_grad_enabled() and hip.kernel_grad_fusion()
+                and (x.requires_grad or y.requires_grad)):
+            flags = hip.FLAG_XDL16
+        build = lambda u, w, r: _LazyKernel(name, u, w, blur, r, flags)  # noqa: E731
     else:
         dense = kernel_routines[name] if kernel is None else kernel
         build = lambda u, w, r: dense(u, w, blur=blur)  # noqa: E731
