@@ -18,6 +18,10 @@ Restated (paths under /root/reference/src/geomloss/_legacy/):
                          ``oracle_np.sinkhorn_loop`` (pinned against the reference's golden outputs), run
                          with this module's soft-min as its plug-in; closed-form gradient of Appendix A.
 * ``kernel_loss``        kernel_loss, kernel_samples.py:92-146, with the closed-form gradient.
+* ``sinkhorn_multiscale`` the two-scale algorithm (sinkhorn_samples.py:453-681) at full size: same statements as
+                         ``oracle_np.sinkhorn_multiscale`` (whose clustering, loop and truncation rule it reuses), with the
+                         fine-level block-sparse reductions evaluated cluster by cluster in float64 on the device
+                         instead of on dense masked matrices.
 
 Pinning: ``tests/test_oracle_golden.py::test_torch64_*`` checks every function here against
 ``oracle_np`` (<= 1e-11) and against the reference-generated golden vectors (<= 1e-8 / 1e-7).
@@ -233,3 +237,136 @@ def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, grad=Fa
     # DoubleGrad (kernel_samples.py:43-54) doubles the half of the symmetric term that autograd sees
     gx = kconv_grad_x(name, xt, xt, a, a, blur, device) - kconv_grad_x(name, xt, yt, b, a, blur, device)
     return loss, gx, a_x - b_x
+
+
+# --------------------------------------------------------------------------------------------------
+#  two-scale Sinkhorn at full size
+# --------------------------------------------------------------------------------------------------
+
+
+class _FineCost:
+    """Fine-level cost object: cluster-sorted clouds (device, float64) + an optional cluster-level keep mask."""
+
+    def __init__(self, x, y, ranges_x, ranges_y, keep=None):
+        self.x, self.y, self.ranges_x, self.ranges_y, self.keep = x, y, ranges_x, ranges_y, keep
+        if keep is not None:
+            ny = torch.as_tensor(ranges_y[:, 1] - ranges_y[:, 0], device=y.device)
+            self.col_label = torch.repeat_interleave(torch.arange(len(ranges_y), device=y.device), ny)
+
+
+def _block_rows(eps, Cobj, h, p, fn):
+    """Applies ``fn(rows r0:r1, column selector or None)`` over the row clusters of a (possibly truncated) fine cost."""
+    if Cobj.keep is None:
+        return fn(slice(0, Cobj.x.shape[0]), None)
+    keep = torch.as_tensor(Cobj.keep, device=Cobj.x.device)
+    outs = []
+    for k, (r0, r1) in enumerate(Cobj.ranges_x):
+        cols = keep[k][Cobj.col_label].nonzero().view(-1)
+        outs.append(fn(slice(int(r0), int(r1)), cols))
+    return outs
+
+
+def _softmin_obj(eps, Cobj, h, p, device):
+    if isinstance(Cobj, dict):                      # coarse level: dense NumPy matrices of oracle_np
+        return oracle_np.softmin_dense(eps, Cobj["C"], h)
+    ht = _t(h, device)
+
+    def fn(rows, cols):
+        if cols is None:
+            return softmin(eps, Cobj.x[rows], Cobj.y, ht, p=p, device=device)
+        if cols.numel() == 0:
+            return np.full(rows.stop - rows.start, np.inf)
+        return softmin(eps, Cobj.x[rows], Cobj.y[cols], ht[cols], p=p, device=device)
+
+    out = _block_rows(eps, Cobj, h, p, fn)
+    return out if isinstance(out, np.ndarray) else np.concatenate(out)
+
+
+def _softmin_grad_obj(eps, Cobj, h, g, p, device):
+    ht, gt = _t(h, device), _t(g, device)
+
+    def fn(rows, cols):
+        if cols is None:
+            return softmin_grad_x(eps, Cobj.x[rows], Cobj.y, ht, gt[rows], p=p, device=device)
+        return softmin_grad_x(eps, Cobj.x[rows], Cobj.y[cols], ht[cols], gt[rows], p=p, device=device)
+
+    out = _block_rows(eps, Cobj, h, p, fn)
+    return out if isinstance(out, np.ndarray) else np.concatenate(out)
+
+
+def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5, cluster_scale=None,
+                        debias=True, potentials=False, grad=False, device=None, return_info=False):
+    """``SamplesLoss("sinkhorn", backend="multiscale")`` for one pair of clouds at any size: the coarse level on dense NumPy
+    matrices exactly as ``oracle_np.sinkhorn_multiscale`` (C ~ 2e3 clusters), the fine level cluster by cluster on the device."""
+    device = default_device() if device is None else device
+    a, x, b, y = (_host64(t) for t in (a, x, b, y))
+    N, D = x.shape
+    diameter, eps, eps_list, rho = oracle_np.scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+    if cluster_scale is None:
+        cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
+    a_c, a, x_c, x, ranges_x, perm_x = oracle_np.clusterize(a, x, cluster_scale)
+    b_c, b, y_c, y, ranges_y, perm_y = oracle_np.clusterize(b, y, cluster_scale)
+    jumps, eps_cost = [len(eps_list) - 1], eps
+    for i, e in enumerate(eps_list[2:]):
+        eps_cost = e                                   # the reference's shadowed `eps` (sinkhorn_samples.py:593-597)
+        if cluster_scale**p > e:
+            jumps = [i + 1]
+            break
+    xt, yt = _t(x, device), _t(y, device)
+    info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), kept_fraction=[], eps_list=eps_list)
+
+    def coarse(u, v, ru, rv):
+        return dict(C=oracle_np.cost_matrix(u, v, p), x=u, y=v, ranges_x=ru, ranges_y=rv)
+
+    def sm(eps_, Cobj, h):
+        return _softmin_obj(eps_, Cobj, h, p, device)
+
+    def kernel_truncation(C_xy, C_yx, C_xy_f, C_yx_f, f, g, eps_, truncate=None, cost=None):
+        if truncate is None:
+            return C_xy_f, C_yx_f
+        keep = f[:, None] + g[None, :] > C_xy["C"] - truncate * eps_            # sinkhorn_samples.py:512-514
+        ni, nj = np.diff(C_xy["ranges_x"], axis=1)[:, 0], np.diff(C_xy["ranges_y"], axis=1)[:, 0]
+        info["kept_fraction"].append(float((ni[:, None] * nj[None, :] * keep).sum() / (ni.sum() * nj.sum())))
+        return (_FineCost(C_xy_f.x, C_xy_f.y, C_xy["ranges_x"], C_xy["ranges_y"], keep),
+                _FineCost(C_yx_f.x, C_yx_f.y, C_xy["ranges_y"], C_xy["ranges_x"], keep.T.copy()))
+
+    extrapolations = []
+
+    def extrapolate(f, g, eps_, lam, C_xy, b_log, C_xy_f):                       # :533-544
+        h = b_log + g / eps_
+        extrapolations.append((eps_, C_xy_f.x, _t(C_xy["y"], device), h))
+        return lam * softmin(eps_, C_xy_f.x, C_xy["y"], h, p=p, device=device)
+
+    C_xys = [coarse(x_c, y_c, ranges_x, ranges_y), _FineCost(xt, yt, ranges_x, ranges_y)]
+    C_yxs = [coarse(y_c, x_c, ranges_y, ranges_x), _FineCost(yt, xt, ranges_y, ranges_x)]
+    C_xxs = [coarse(x_c, x_c, ranges_x, ranges_x), _FineCost(xt, xt, ranges_x, ranges_x)] if debias else None
+    C_yys = [coarse(y_c, y_c, ranges_y, ranges_y), _FineCost(yt, yt, ranges_y, ranges_y)] if debias else None
+    lw = oracle_np.log_weights
+    pots, last = oracle_np.sinkhorn_loop(sm, [lw(a_c), lw(a)], [lw(b_c), lw(b)], C_xxs, C_yys, C_xys, C_yxs, eps_list, rho,
+                                         jumps=jumps, kernel_truncation=kernel_truncation, truncate=truncate,
+                                         extrapolate=extrapolate, debias=debias)
+    f_aa, g_bb, g_ab, f_ba = pots
+    out = oracle_np.sinkhorn_cost(eps_cost, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
+    if potentials:
+        F, G = out
+        f_x, g_y = np.empty_like(F), np.empty_like(G)
+        f_x[perm_x], g_y[perm_y] = F, G
+        out = (f_x, g_y)
+    else:
+        out = float(out)
+    if grad:
+        assert rho is None and not potentials
+        if "h_ba" in last:
+            gs = _softmin_grad_obj(last["eps"], last["C_xy"], last["h_ba"], a, p, device)
+            if debias:
+                gs = gs - _softmin_grad_obj(last["eps"], last["C_xx"], last["h_aa"], a, p, device)
+        else:
+            e, xf, yc, h = extrapolations[0]
+            gs = softmin_grad_x(e, xf, yc, h, a, p=p, device=device)
+            if debias:
+                e, xf, xc, h = extrapolations[2]
+                gs = gs - softmin_grad_x(e, xf, xc, h, a, p=p, device=device)
+        gx = np.empty_like(gs)
+        gx[perm_x] = gs
+        out = (out, gx)
+    return (out, info) if return_info else out

@@ -228,6 +228,24 @@ def test_block_sparse_fwd_bwd_1e6_with_real_truncation_ranges(cuda):
         assert np.abs(out_t[torch.from_numpy(rows).to(cuda)].cpu().numpy() - ref).max() < 1.5e-6, k
 
 
+@pytest.mark.parametrize("N", [200_000])
+def test_cfg3_multiscale_end_to_end_vs_two_scale_oracle(cuda, N):
+    """BASELINE configs[2] end to end — clustering, coarse loop, kernel truncation, extrapolation, truncated fine loop — against
+    the float64 two-scale oracle (fine level cluster by cluster on the GPU), at a size the oracle finishes in seconds.  The same
+    comparison at N = M = 1e6 (2 minutes of float64 work) is `tools/verify_cfg3.py`; its output is profiles/r02_cfg3_parity.txt."""
+    x, y = _uniform_clouds(23, N, N, cuda, shift=True)
+    kw = dict(p=2, blur=0.05)
+    a = np.full(N, 1.0 / N)
+    (ref, ref_gx), info = o64.sinkhorn_multiscale(a, x, a, y, grad=True, return_info=True, device=cuda, **kw)
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(xg, y)
+    (gx,) = torch.autograd.grad(L, [xg])
+    e = (abs(L.item() - ref) / abs(ref), relerr(gx.cpu().numpy(), ref_gx))
+    print(f"cfg3 N={N}: loss {L.item():.9e} oracle {ref:.9e} rel {e[0]:.2e}; dL/dx rel {e[1]:.2e}; kept {info['kept_fraction']}")
+    assert 0 < info["kept_fraction"][0] < 1 and info["jumps"][0] < len(info["eps_list"]) - 1
+    assert e[0] < 1e-4 and e[1] < 1e-4
+
+
 def G_fine(gen, M, dev):
     """A smooth-ish dual potential of realistic size (|g| <~ diam^2 / 2) plus noise."""
     return (0.05 * torch.randn(M, generator=gen)).to(dev)

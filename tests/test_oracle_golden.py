@@ -169,3 +169,20 @@ def test_torch_port_matches_reference():
         assert abs(L64 - float(rec["loss_f64"])) <= 1e-9 * abs(float(rec["loss_f64"]))
         L32 = sinkhorn_tensorized_cpu(x.float(), y.float(), p=kw["p"], blur=kw["blur"], scaling=kw.get("scaling", 0.5)).item()
         assert abs(L32 - float(rec["loss_f32"])) <= 2e-5 * abs(float(rec["loss_f32"]))
+
+
+def test_torch64_two_scale_oracle_equals_the_dense_masked_one():
+    """oracle_torch64.sinkhorn_multiscale (fine level cluster by cluster: what runs at N = 1e6 on the test GPU) against
+    oracle_np.sinkhorn_multiscale (dense masked matrices) on problems small enough for both."""
+    rng = np.random.default_rng(3)
+    N, M = 700, 640
+    x, y = rng.random((N, 3)), rng.random((M, 3)) * 0.6 + 0.3
+    a, b = np.full(N, 1 / N), np.full(M, 1 / M)
+    for kw in (dict(scaling=0.7), dict(scaling=0.7, truncate=2), dict(diameter=1.0, cluster_scale=0.1), dict(scaling=0.7, debias=False)):
+        (r, g), i1 = oracle_np.sinkhorn_multiscale(a, x, b, y, grad=True, return_info=True, **kw)
+        (r2, g2), i2 = oracle_torch64.sinkhorn_multiscale(a, x, b, y, grad=True, return_info=True, device=CPU, **kw)
+        assert abs(r - r2) <= 1e-12 * abs(r) and relerr(g2, g) < 1e-11
+        assert np.allclose(i1["kept_fraction"], i2["kept_fraction"], rtol=1e-12) and i1["jumps"] == i2["jumps"]
+        F, G = oracle_np.sinkhorn_multiscale(a, x, b, y, potentials=True, **kw)
+        F2, G2 = oracle_torch64.sinkhorn_multiscale(a, x, b, y, potentials=True, device=CPU, **kw)
+        assert np.abs(F - F2).max() < 1e-12 and np.abs(G - G2).max() < 1e-12
