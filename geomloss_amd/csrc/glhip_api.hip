@@ -805,6 +805,44 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
     return check_launch("glhip_kernel_conv_fwd_grad");
 }
 
+int glhip_cmin_fwd(const void* x, const void* y, const float* g, float* out, int B, int N, int M, int D, int p, int in_dtype,
+                   const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                   size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_cmin_fwd", x, y, g, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_cmin_fwd: p must be 1 or 2 (got %d)", p);
+    if (D > 3) return fail(GLHIP_EUNSUPPORTED, "glhip_cmin_fwd: D = %d > 3 is not supported", D);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    if (!out) return fail(GLHIP_EINVAL, "glhip_cmin_fwd: NULL out");
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const CminParams<T> prm{static_cast<const T*>(x), static_cast<const T*>(y), g, out};
+#define GL_CMIN(DD, PP) launch_mapreduce<HardMinOp<DD, PP, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb)
+        if (p == 2) { if (D == 1) GL_CMIN(1, 2); else if (D == 2) GL_CMIN(2, 2); else GL_CMIN(3, 2); }
+        else        { if (D == 1) GL_CMIN(1, 1); else if (D == 2) GL_CMIN(2, 1); else GL_CMIN(3, 1); }
+#undef GL_CMIN
+    };
+    if (in_dtype == GLHIP_F32) run(float{}); else run(bf16_t{});
+    return check_launch("glhip_cmin_fwd");
+}
+
+int glhip_max_lines_fwd(const float* g, float* out, long R, int N, float step, int p, void* stream) {
+    if (R < 0 || N < 0) return fail(GLHIP_EINVAL, "glhip_max_lines_fwd: negative size (R=%ld, N=%d)", R, N);
+    if (R == 0 || N == 0) return GLHIP_OK;
+    if (!g || !out) return fail(GLHIP_EINVAL, "glhip_max_lines_fwd: NULL pointer");
+    if (N > kLineMax) return fail(GLHIP_EUNSUPPORTED, "glhip_max_lines_fwd: lines of more than %d samples are not supported (N=%d)", kLineMax, N);
+    if (!(step > 0.f)) return fail(GLHIP_EINVAL, "glhip_max_lines_fwd: step must be > 0");
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_max_lines_fwd: p must be 1 or 2 (got %d)", p);
+    const unsigned grid = (unsigned)(R < 262144 ? R : 262144);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p == 2) hipLaunchKernelGGL((max_lines_kernel<2>), dim3(grid), dim3(kBlock), 0, st, g, out, R, N, step);
+    else hipLaunchKernelGGL((max_lines_kernel<1>), dim3(grid), dim3(kBlock), 0, st, g, out, R, N, step);
+    return check_launch("glhip_max_lines_fwd");
+}
+
 int glhip_softmin_dense_fwd(const float* C, const float* h, float* out, int B, int N, int M, float eps,
                             void* stream) {
     if (B < 0 || N < 0 || M < 0) return fail(GLHIP_EINVAL, "glhip_softmin_dense_fwd: bad sizes");

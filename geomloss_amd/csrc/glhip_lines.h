@@ -62,6 +62,24 @@ lse_lines_fwd_kernel(const float* __restrict__ h, float* __restrict__ out, long 
     }
 }
 
+// hard C-transform along the lines of a grid:  out[r, i] = max_j [ g[r, j] - c(i, j) ],  c = (step (i-j))^2 or step |i-j| in
+// natural units — `C_transform`, _legacy/utils.py:116-182 (KeOps LazyTensor.max there).
+template <int P>
+__global__ void __launch_bounds__(kBlock)
+max_lines_kernel(const float* __restrict__ g, float* __restrict__ out, long R, int N, float step) {
+    __shared__ float gs[kLineMax];
+    for (long r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < N; j += kBlock) gs[j] = g[r * N + j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += kBlock) {
+            float best = -3.0e38f;
+            for (int j = 0; j < N; ++j) best = fmaxf(best, gs[j] - line_cost<P>(i, j, step));
+            out[r * N + i] = best;
+        }
+    }
+}
+
 template <int P>
 __global__ void __launch_bounds__(kBlock)
 lse_lines_bwd_kernel(const float* __restrict__ h, const float* __restrict__ lse, const float* __restrict__ g,

@@ -110,6 +110,98 @@ __device__ __forceinline__ float pair_exponent(const float (&a)[D], const Rec<D>
     }
 }
 
+// ---- hard C-transform (the eps -> 0 limit of the soft-min) -------------------------------------------------------
+//   out_i = min_j [ C(x_i, y_j) - g_j ],  C = |x-y|^2 / 2 (P = 2) or sqrt(max(|x-y|^2, 1e-8)) (P = 1), on explicit differences,
+// natural units.  The eps = 0 branch of the reference's softmin_sample (ot/_implementations/sample.py:156-166).
+
+template <typename T>
+struct CminParams {
+    const T* x;        // (B,N,D)
+    const T* y;        // (B,M,D)
+    const float* g;    // (B,M)
+    float* out;        // (B,N)
+};
+
+template <int D_, int P, int R, typename T>
+struct HardMinOp {
+    static constexpr int kDim = D_;
+    static constexpr int kRows = R;
+    static constexpr int kPartial = 1;
+    using Params = CminParams<T>;
+    struct RowState {
+        float a[R][D_];
+        float best[R];
+    };
+    static constexpr float kHuge = 3.0e38f;
+
+    static __device__ __forceinline__ void load_centre(const Params& p, int b, int N, int row0, float (&c)[D_]) {
+        centre_of<D_, T>(p.x, b, N, row0, c);
+    }
+    static __device__ __forceinline__ void init_rows(const Params& p, int b, int N, int row0, int row_end, int tid,
+                                                     const float (&c)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = min(row0 + r * kBlock + tid, row_end - 1);
+            float xi[D_];
+            load_point<D_, T>(p.x, (long)b * N + i, xi);
+#pragma unroll
+            for (int d = 0; d < D_; ++d) st.a[r][d] = xi[d] - c[d];
+            st.best[r] = kHuge;
+        }
+    }
+    static __device__ __forceinline__ Rec<D_> make_record(const Params& p, int b, int M, int j, const float (&c)[D_]) {
+        float yj[D_];
+        load_point<D_, T>(p.y, (long)b * M + j, yj);
+        Rec<D_> rec;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) rec.c[d] = yj[d] - c[d];
+        rec_tail<D_>(rec) = p.g[(long)b * M + j];
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+    static __device__ __forceinline__ Rec<D_> neutral_record() {
+        Rec<D_> rec;
+#pragma unroll
+        for (int d = 0; d < D_; ++d) rec.c[d] = 0.f;
+        rec_tail<D_>(rec) = -kHuge;      // C - g = +huge: never the minimum
+        if (D_ == 2) rec.c[3] = 0.f;
+        return rec;
+    }
+    static __device__ __forceinline__ void consume(RowState& st, const Rec<D_>* __restrict__ recs) {
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) {
+            const Rec<D_> rc = recs[c];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float d2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D_; ++d) {
+                    const float df = st.a[r][d] - rc.c[d];
+                    d2 = __builtin_fmaf(df, df, d2);
+                }
+                const float C = (P == 2) ? 0.5f * d2 : fast_sqrt(fmaxf(d2, 1e-8f));
+                st.best[r] = fminf(st.best[r], C - rec_tail<D_>(rc));
+            }
+        }
+    }
+    static __device__ __forceinline__ float value(float best) { return best > 1.0e37f ? __builtin_inff() : best; }   // empty set
+    static __device__ __forceinline__ void finish_rows(const Params& p, int b, int N, int row0, int row_end, int tid,
+                                                       const float (&)[D_], RowState& st) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r * kBlock + tid;
+            if (i < row_end) p.out[(long)b * N + i] = value(st.best[r]);
+        }
+    }
+    static __device__ __forceinline__ void store_partial(const RowState& st, int r, float* dst) { dst[0] = st.best[r]; }
+    static __device__ __forceinline__ void merge_row(const Params& p, int b, int N, int i, const float (&)[D_],
+                                                     const float* part, int ns, long stride) {
+        float best = kHuge;
+        for (int k = 0; k < ns; ++k) best = fminf(best, part[k * stride]);
+        p.out[(long)b * N + i] = value(best);
+    }
+};
+
 // ---- forward ----------------------------------------------------------------------------------
 
 template <int D_, int P, bool DIRECT, int R, typename T>

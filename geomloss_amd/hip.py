@@ -47,6 +47,8 @@ SIGNATURES = {
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
     "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_lse_lines_bwd": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
+    "glhip_cmin_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int] + _RANGES + _TAIL),
+    "glhip_max_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_cluster_workspace_bytes": (_c_size, [_c_int, _c_int]),
     "glhip_grid_cluster": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, _c_float] + [_vp] * 7 + [_vp, _c_size, _vp]),
     "glhip_block_ranges": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 6
@@ -649,6 +651,38 @@ class _LseLines(torch.autograd.Function):
                                          eps, p, _stream(hc))
         _check(rc, lib)
         return gh.to(dtype), None, None
+
+
+def cmin(x, y, g, p=2, ranges=None, flags=0):
+    """Hard C-transform on the GPU: min_j [C(x_i, y_j) - g_j], C = |x-y|^2/2 (p = 2) or |x-y| (p = 1); not differentiable.
+    x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), g: (M,)|(B,M) -> (N,)|(B,N) fp32."""
+    lib = load_library()
+    xb, yb, gb, batched = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(g))
+    if yb.dtype != xb.dtype:
+        yb = yb.to(xb.dtype)
+    B, N, D = xb.shape
+    M = yb.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device):
+        ws, ws_args = _workspace(lib, xb, B, N, M, D, ranges)
+        rc = lib.glhip_cmin_fwd(xb.data_ptr(), yb.data_ptr(), gb.data_ptr(), out.data_ptr(), B, N, M, D, int(p), _dtype_code(xb),
+                                *_range_args(ranges, B), *ws_args, int(flags) | ENV_FLAGS, _stream(xb))
+    _check(rc, lib)
+    return out if batched else out.view(-1)
+
+
+def max_lines(g, step, p=2):
+    """out[..., i] = max_j [g[..., j] - c(i, j)] along the last axis, c = (step (i-j))^2 (p = 2) or step |i-j| (p = 1)."""
+    if not g.is_cuda:
+        raise RuntimeError("geomloss_amd: the grid C-transform runs on the HIP kernels only; move the arrays to a GPU.")
+    gc = g.detach().float().contiguous()
+    N = gc.shape[-1]
+    out = torch.empty_like(gc)
+    lib = load_library()
+    with torch.cuda.device(gc.device):
+        rc = lib.glhip_max_lines_fwd(gc.data_ptr(), out.data_ptr(), gc.numel() // max(N, 1), N, float(step), int(p), _stream(gc))
+    _check(rc, lib)
+    return out.to(g.dtype)
 
 
 def lse_lines(h, eps, p=2):

@@ -140,8 +140,8 @@ def softmin_sample(eps, log_weights, costs, potentials):
     """``f_i = -eps log sum_j exp(log_b_j + (g_j - |x_i - y_j|^2) / eps)`` (``sample.py:91-180``) on the GPU.
 
     ``costs`` is a :class:`SampleCost`-like pair ``(x, y)`` of clouds instead of a LazyTensor.  ``eps = inf`` is the weighted
-    mean of ``C - g``; ``eps = 0`` (the hard C-transform, a min-reduction) is not reachable from ``solve_sample`` — the
-    reference's solver refuses ``reg = 0`` — and is not implemented on the kernels.
+    mean of ``C - g`` (three moments of the column cloud), ``eps = 0`` the hard C-transform ``min_j (C_ij - g_j)``
+    (``glhip_cmin_fwd``; not reachable from ``solve_sample``, whose argument check refuses ``reg = 0`` like the reference's).
     """
     x, y = (costs.x, costs.yd) if isinstance(costs, SampleCost) else costs
     eps = float(eps)
@@ -150,8 +150,8 @@ def softmin_sample(eps, log_weights, costs, potentials):
         from .sinkhorn_ot import _mean_cost
         b = log_weights.exp()
         return 2.0 * _mean_cost(x, y, b) - (potentials * b).sum() / b.sum()
-    if eps == 0:
-        raise NotImplementedError("geomloss_amd: the eps = 0 (hard C-transform) branch of softmin_sample has no HIP kernel.")
+    if eps == 0:     # hard C-transform: min_j (|x_i - y_j|^2 - g_j) = 2 min_j (|x_i - y_j|^2 / 2 - g_j / 2)   (glhip_cmin_fwd)
+        return 2.0 * hip.cmin(x, y, 0.5 * potentials, p=2)
     return 2.0 * hip.softmin(eps / 2, x, y.detach(), (log_weights + potentials / eps).detach())
 
 

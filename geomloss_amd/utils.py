@@ -69,6 +69,28 @@ def log_dens(α):
     return α_log
 
 
+def C_transform(G, tau=1, p=2):
+    """Hard C-transform of an array on a regular grid with unit pixels (``utils.py:116-182``):
+    ``F(x_i) = max_j [G(x_j) - |x_i - x_j|^p / (p tau)]`` for G of shape (B,N), (B,N,N) or (B,N,N,N), one separable pass of the
+    HIP kernel ``glhip_max_lines_fwd`` per axis.  Like the reference — whose ``if p == 1 / if p == 2 / else`` chain sends p = 1
+    to the ``else`` — only p = 2 is accepted."""
+    import numpy as np
+
+    from . import hip
+
+    if p != 2:
+        raise NotImplementedError()
+    D = G.ndim - 1
+    if D not in (1, 2, 3):
+        raise ValueError("C_transform expects (B,N), (B,N,N) or (B,N,N,N) arrays.")
+    step = 1.0 / np.sqrt(2 * tau)                         # x = arange(N) / sqrt(2 tau), cost (x_i - x_j)^2
+    last = G.dim() - 1
+    out = hip.max_lines(G, step, p)
+    for axis in range(last - 1, 0, -1):
+        out = hip.max_lines(out.transpose(axis, last), step, p).transpose(axis, last)
+    return out
+
+
 def softmin_grid(eps, C_xy, h_y):
     """Soft-C-transform on a grid, one separable log-sum-exp pass per axis (``utils.py:190-279``).
 

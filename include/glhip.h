@@ -225,6 +225,19 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
                                const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
                                void* workspace, size_t workspace_bytes, int flags, void* stream);
 /*
+ * Hard C-transforms — the eps -> 0 limits of the two soft-mins above (min / max reductions, no exponential).
+ *   glhip_cmin_fwd:       out[b,i] = min_j [ C(x[b,i], y[b,j]) - g[b,j] ],  C = |x-y|^2/2 (p = 2) or |x-y| (p = 1), D <= 3;
+ *                         +inf over an empty column set.  Replaces the `eps == 0` branch of softmin_sample
+ *                         (ot/_implementations/sample.py:156-166: `(C_xy - g_y_j).min(axis=1)` on a LazyTensor).
+ *   glhip_max_lines_fwd:  out[r,i] = max_j [ g[r,j] - c(i,j) ],  c = (step (i-j))^2 (p = 2) or step |i-j| (p = 1), for R lines
+ *                         of N <= 4096 samples.  Replaces the LazyTensor `.max(dim=2)` of `C_transform`
+ *                         (_legacy/utils.py:116-182), applied once per image axis.
+ */
+int glhip_cmin_fwd(const void* x, const void* y, const float* g, float* out, int B, int N, int M, int D, int p, int in_dtype,
+                   const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                   void* workspace, size_t workspace_bytes, int flags, void* stream);
+int glhip_max_lines_fwd(const float* g, float* out, long R, int N, float step, int p, void* stream);
+/*
  * The cluster pyramid of the two-scale ("multiscale") backends, on the device.
  *
  * glhip_grid_cluster — voxel clustering of a weighted cloud.  Replaces the chain

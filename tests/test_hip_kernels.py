@@ -447,6 +447,30 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias):
     assert rc == -1 and b"alias" in lib.glhip_last_error()
 
 
+@pytest.mark.parametrize("N,M,D,B", [(300, 257, 3, None), (1030, 70_001, 2, None), (257, 300, 1, 3)])
+@pytest.mark.parametrize("p", [2, 1])
+def test_hard_c_transform_vs_numpy(cuda, N, M, D, B, p):
+    """glhip_cmin_fwd: min_j [C(x_i,y_j) - g_j] — dense, many columns (column splits + min-merge), batched, block-sparse."""
+    x, y, g = _clouds(61 + N, N, M, D, B=B)
+    C = oracle_np.cost_matrix(x.astype(np.float64), y.astype(np.float64), p)
+    ref = (C - g.astype(np.float64)[..., None, :]).min(-1)
+    out = hip.cmin(_t(x, cuda), _t(y, cuda), _t(g, cuda), p=p).cpu().numpy()
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
+    if B is None and M < 5000:
+        rng = np.random.default_rng(1)
+        rg, tup, _, keep, ri = _random_ranges(rng, N, M, 5, 6, 0.5, cuda)
+        outs = hip.cmin(_t(x, cuda), _t(y, cuda), _t(g, cuda), p=p, ranges=rg).cpu().numpy()
+        mask = np.zeros((N, M), bool)
+        sl, red = tup[1], tup[2]
+        for k, (r0, r1) in enumerate(tup[0]):
+            for q in range(sl[k - 1] if k else 0, sl[k]):
+                mask[r0:r1, red[q][0]:red[q][1]] = True
+        refs = np.where(mask, C - g[None, :], np.inf).min(-1)
+        assert np.isposinf(outs[ri[0, 0]:ri[0, 1]]).all()
+        live = np.isfinite(refs)
+        assert np.abs(outs[live] - refs[live]).max() < 3e-6 * max(1.0, np.abs(refs[live]).max())
+
+
 def test_empty_clouds(cuda):
     """N = 0 returns an empty result; M = 0 is the reduction over the empty set (+inf potential, zero kernel sum)."""
     x, y0 = torch.rand(5, 3, device=cuda), torch.rand(0, 3, device=cuda)

@@ -135,3 +135,21 @@ def test_image_loop_replayed_from_a_hipgraph(cuda):
         for (L0, g0), (L1, g1) in zip(eager, run):
             assert (L0 - L1).abs().max().item() <= 1e-7 * L0.abs().max().item()
             assert (g0 - g1).abs().max().item() <= 1e-6 * g0.abs().max().item()
+
+
+def test_hard_c_transform_on_grids(cuda):
+    """utils.C_transform (glhip_max_lines_fwd, one pass per axis) against the dense definition
+    F(x_i) = max_j [G(x_j) - |x_i - x_j|^2 / (2 tau)] on 1-D, 2-D and 3-D grids (_legacy/utils.py:116-182)."""
+    from geomloss_amd.utils import C_transform
+
+    g = torch.Generator().manual_seed(0)
+    for shape, tau in (((3, 37), 1.0), ((2, 24, 24), 2.5), ((2, 9, 9, 9), 0.7)):
+        G = torch.randn(shape, generator=g).to(cuda) * 3
+        out = C_transform(G, tau=tau, p=2).double().cpu()
+        D, N = len(shape) - 1, shape[1]
+        grid = torch.stack(torch.meshgrid(*([torch.arange(N, dtype=torch.float64)] * D), indexing="ij"), -1).reshape(-1, D)
+        C = ((grid[:, None, :] - grid[None, :, :]) ** 2).sum(-1) / (2 * tau)
+        ref = (G.double().cpu().reshape(shape[0], 1, -1) - C[None]).max(-1)[0].reshape(shape)
+        assert (out - ref).abs().max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        C_transform(torch.zeros(1, 8, device=cuda), p=1)

@@ -130,8 +130,8 @@ def test_softmin_sample_branches(cuda):
     for eps in (float("inf"), 0.3, 0.01):
         got = ot.softmin_sample(eps, lb, (xt, yt), gt).cpu().numpy()
         assert relerr(got, oracle_ot.softmin(eps, np.log(b), C, g)) < 2e-5, eps
-    with pytest.raises(NotImplementedError):
-        ot.softmin_sample(0, lb, (xt, yt), gt)
+    got = ot.softmin_sample(0, lb, (xt, yt), gt).cpu().numpy()                # hard C-transform
+    assert relerr(got, oracle_ot.softmin(0, np.log(b), C, g)) < 2e-6
 
 
 def test_large_problem_and_gradient(cuda):
