@@ -1,0 +1,55 @@
+// glhip_api_convgrad.hip — C-ABI part 4: gradients of the kernel products.
+#include "glhip_launch.h"
+
+extern "C" {
+
+int glhip_kernel_conv_bwd_x(int kind, const void* x, const void* y, const float* v, const float* g, float* grad_x,
+                            int B, int N, int M, int D, float blur, int in_dtype, const int32_t* ranges_i,
+                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                            size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_kernel_conv_bwd_x", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GLHIP_OK;   // nothing to write
+    if (!g || !grad_x) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: NULL g / grad_x");
+    if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: bad kind %d", kind);
+    if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_bwd_x: blur must be > 0");
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
+    rc = (in_dtype == GLHIP_F32)
+             ? conv_typed<true, float>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st)
+             : conv_typed<true, bf16_t>(kind, x, y, v, nullptr, g, grad_x, B, N, M, D, blur, rg, n_ranges, sc, flags, st);
+    return rc ? rc : check_launch("glhip_kernel_conv_bwd_x");
+}
+
+int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const float* v, float* out, float* grad_unit,
+                               int B, int N, int M, int D, float blur, int in_dtype, const int32_t* ranges_i,
+                               const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                               size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_kernel_conv_fwd_grad", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (kind != GLHIP_GAUSSIAN || D > 3 || (flags & GLHIP_FLAG_NO_MFMA))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: only the gaussian kernel, D <= 3, on the matrix-core kernels "
+                                        "(got kind %d, D %d, flags %d): call glhip_kernel_conv_fwd + glhip_kernel_conv_bwd_x", kind, D, flags);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    if (!out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: NULL out / grad_unit");
+    if (!(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        ConvParams<T> prm;
+        prm.x = static_cast<const T*>(x); prm.y = static_cast<const T*>(y); prm.v = v; prm.out = out; prm.g = nullptr; prm.gx = grad_unit;
+        prm.t = std::sqrt(0.5f * kLog2e) / blur;
+        prm.gscale = -1.0f / (prm.t * blur * blur);
+        prm.clamp2 = 0.f;
+        if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        else launch_gauss_fwdgrad<3, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+    };
+    if (in_dtype == GLHIP_F32) run(float{}); else run(bf16_t{});
+    return check_launch("glhip_kernel_conv_fwd_grad");
+}
+
+}  // extern "C"

@@ -1,0 +1,563 @@
+// glhip_launch.h — host side shared by the translation units of libgeomloss_hip.so: argument checks, scratch layout, kernel
+// selection and launch templates.  Everything lives in an anonymous namespace on purpose: each .hip file includes this header and
+// instantiates only the templates its entry points use (forward / gradient / kernel-product kernels compile in parallel).
+#pragma once
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "glhip_error.h"
+#include "glhip_generic.h"
+#include "glhip_kconv_ops.h"
+#include "glhip_softmin_ops.h"
+#include "glhip_softmin_mfma.h"
+#include "glhip_wsum_mfma.h"
+#include "glhip_softmin_xdl.h"
+#include "glhip_softmin_x32.h"
+#include "glhip_wsum_x32.h"
+
+using namespace glhip;
+
+namespace {
+
+int check_common(const char* fn, const void* x, const void* y, const void* s, int B, int N, int M, int D,
+                 int in_dtype, const int32_t* ri, const int32_t* si, const int32_t* rj, int n_ranges) {
+    if (B < 0 || N < 0 || M < 0 || D < 1) return fail(GLHIP_EINVAL, "%s: bad sizes B=%d N=%d M=%d D=%d", fn, B, N, M, D);
+    // empty clouds may come with NULL pointers (a torch tensor with no elements has none)
+    if ((!x && (long)B * N > 0) || ((!y || !s) && (long)B * M > 0)) return fail(GLHIP_EINVAL, "%s: NULL input pointer", fn);
+    if (in_dtype != GLHIP_F32 && in_dtype != GLHIP_BF16) return fail(GLHIP_EINVAL, "%s: bad in_dtype %d", fn, in_dtype);
+    if (n_ranges < 0) return fail(GLHIP_EINVAL, "%s: n_ranges < 0", fn);
+    if (n_ranges > 0) {
+        if (!ri || !si || !rj) return fail(GLHIP_EINVAL, "%s: block-sparse mode needs ranges_i, slices_i, redranges_j", fn);
+        if (B != 1) return fail(GLHIP_EUNSUPPORTED, "%s: block-sparse mode requires B == 1 (got %d)", fn, B);
+    }
+    if (B > 65535) return fail(GLHIP_EUNSUPPORTED, "%s: B=%d exceeds the grid.y limit 65535", fn, B);
+    return GLHIP_OK;
+}
+
+struct Scratch {
+    void* ws;
+    size_t bytes;
+    bool allow_split;
+    bool force_pre;     // GLHIP_FLAG_PREPACK
+    ChunkBuf cb;        // block-sparse launches: room for the row-chunk table, carved off the front of the workspace
+    // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
+    // GLHIP_FLAG_NO_SPLIT tells us to leave alone
+    bool prepack(double pairs) const { return ws && (force_pre || (allow_split && pairs >= 5e8)); }
+};
+
+// Scratch of one API call.  Block-sparse calls reserve the front of the workspace for the row-chunk table (sized for the
+// smallest row tile, 128 rows); the rest serves the column splits and the packed columns as before.
+Scratch make_scratch(void* workspace, size_t bytes, int flags, int n_ranges, int N) {
+    Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0, ChunkBuf()};
+    if (n_ranges > 0 && workspace) {
+        const size_t need = chunk_table_bytes(n_ranges, N, 128);
+        if (bytes >= need) {
+            sc.cb.buf = static_cast<int32_t*>(workspace);
+            sc.cb.capacity = (long)n_ranges + N / 128 + 1;
+            sc.ws = static_cast<char*>(workspace) + need;
+            sc.bytes = bytes - need;
+            if (sc.bytes == 0) sc.ws = nullptr;
+        }
+    }
+    return sc;
+}
+
+// rows per thread: 2 keeps the LDS read rate at half a ds_read_b128 per row-column step while leaving
+// enough workgroups to fill 256 CUs; small problems use 1 to expose more workgroups.
+inline bool use_two_rows(int B, int N, int n_ranges, const Scratch& sc) {
+    if (n_ranges > 0) return true;
+    if (sc.ws && sc.allow_split) return (long)B * N >= 4 * kBlock;   // column splits provide the parallelism
+    const long blocks2 = (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
+    return blocks2 >= 1024;
+}
+
+// ---- softmin ---------------------------------------------------------------------------------------
+
+template <int D, int P, bool DIRECT, bool BWD, typename T>
+void launch_softmin_r(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                      const Scratch& sc, hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges, sc)) {
+        if constexpr (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 2, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+    } else {
+        if constexpr (BWD) launch_mapreduce<SoftminBwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+        else launch_mapreduce<SoftminFwdOp<D, P, DIRECT, 1, T>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+    }
+}
+
+// p = 2 forward on the matrix cores (glhip_softmin_mfma.h); same partial format / merge kernel as the VALU op.
+// 2 row tiles per wavefront (128 rows per workgroup): 84-126 VGPRs -> 4-5 waves/SIMD; measured equal to 4 tiles at
+// N=M=1e6 and 11-16 % faster on mid-size, batched and block-sparse problems.
+constexpr int kFwdRT = 2;
+constexpr long kFwdSlots = 256 * 3;   // resident 8-wave workgroups of the forward / gaussian x32 kernels (<= 84 VGPRs, 32 KiB LDS)
+// p = 2 forward on the matrix cores; same partial format / merge kernel as the VALU op.
+//   KIND 0: fp32 MFMA (glhip_softmin_mfma.h), 4 waves.   KIND 1: bf16x3 on 16x16x32 MFMAs (glhip_softmin_xdl.h).
+//   KIND 2: bf16x3 on 32x32x16 MFMAs, transposed blocks (glhip_softmin_x32.h) — the default.
+enum { FWD_F32 = 0, FWD_XDL16 = 1, FWD_X32 = 2 };
+
+template <int D, typename T, int KIND, int NW, bool SPARSE>
+void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp) {
+    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
+    else if (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+    else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+}
+
+template <int D, typename T, int KIND, int NW>
+void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                            const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
+    constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
+    static_assert(kFwdRT == 2, "row tiling of the forward kernels");
+    unsigned chunk_grid = 0;   // block-sparse: one workgroup per row chunk of kRowsPerBlock rows (build_row_chunks_kernel)
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    // the number of column splits is still derived from the number of row BLOCKS: deriving it from the (larger) chunk count
+    // gives fewer, longer-lived workgroups and measured 3 % slower on uniform clusters (multiscale at 1e6: 258 vs 250 ms)
+    const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
+    const long per_split = (long)B * N * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * 2;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+
+    // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
+    // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
+    PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);   // either layout fits
+    auto plan_pre = [&](int ns) {
+        const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
+        if (KIND != FWD_X32 || !sc.prepack((double)B * N * M)) return false;
+        if (sc.bytes < part_bytes + packed_bytes) return false;
+        pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+        return true;
+    };
+    auto pack = [&]() {
+        if (n_ranges > 0) hipLaunchKernelGGL((pack_columns_kernel<D, T, false>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+        else hipLaunchKernelGGL((pack_columns_kernel<D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+    };
+
+    if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
+        // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
+        const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+        const int nx = (KIND == FWD_X32 && sc.prepack((double)B * N * M)) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit)
+                                                                          : xcd_splits((long)gx * B, M, kFwdSlots, fit);
+        const long total = (long)gx * B * nx;
+        if (total < (1L << 31)) {
+            sp.n_splits = nx;
+            sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
+            if (plan_pre(nx)) {
+                pack();
+                hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+            } else {
+                launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
+            }
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+            return;
+        }
+    }
+    if (n_ranges > 0) {
+        if (plan_pre(sp.n_splits)) {
+            pack();
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
+        } else {
+            launch_fwd_kernel<D, T, KIND, NW, true>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
+        }
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+    } else {
+        const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+        if (plan_pre(sp.n_splits)) {
+            pack();
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+        } else {
+            launch_fwd_kernel<D, T, KIND, NW, false>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
+        }
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+    }
+}
+
+template <int D, typename T, int KIND>
+void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                         const Scratch& sc, hipStream_t st) {
+    // Workgroup height of the bf16x3 kernels: 8 wavefronts (256 rows per pass) for launches big enough to run with
+    // pre-packed columns — dense (1-4 % faster than 4 there, measured from B x N = 256 x 4096 to 1 x 1e6) and
+    // block-sparse with row blocks of a few hundred points (multiscale at 1e6: 0.27 vs 0.30 s); 4 wavefronts when
+    // every workgroup packs its own tiles or the row blocks are small, where more, smaller workgroups win.
+    static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
+    if (KIND == FWD_F32)
+        launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (forced_nw ? forced_nw == 8
+                       : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
+        launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 8>(prm, rg, n_ranges, B, N, M, sc, st);
+    else
+        launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 4>(prm, rg, n_ranges, B, N, M, sc, st);
+}
+
+// weighted-sum matrix-core kernels; MergeOp is the VALU operator with the same partial format.
+//   x32 = true: glhip_wsum_x32.h (32x32x16 MFMAs, pre-packed columns when the launch is big enough) — the default;
+//   x32 = false: glhip_wsum_mfma.h (16x16x32 MFMAs, GLHIP_FLAG_XDL16).
+// The 32x32x16 form pays for the one-component reduction (gaussian product: 1 exp2 + 1 fma per pair, 89.8 vs 92.4 ms
+// at 1e6).  With D + 1 accumulators per row it needs 64 accumulator registers per lane and its bare loop measures
+// 22.8 cycles per 64 pairs (tools/ubench/overlap.hip) — what the 16x16x32 kernel already delivers end to end
+// (23.3); the shipped x32 gradient kernels were slower (188 vs 148 ms), so the gradients stay on glhip_wsum_mfma.h.
+template <int MODE> constexpr bool wsum_uses_x32() { return MODE == WS_GAUSS_FWD; }
+
+template <int MODE, int D, typename T, bool SPARSE>
+void launch_wsum_kernel(bool x32, bool pre, dim3 grid, hipStream_t st, const WsumParams<T>& prm, const Ranges& rg, int N, int M,
+                        const SplitInfo& sp, const PackedCols& pk, const PackedQ& pq) {
+    if constexpr (wsum_uses_x32<MODE>()) {
+        if (x32 && pre) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
+        if (x32) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, false>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
+    }
+    hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+}
+
+template <int MODE, int D, typename T, class MergeOp>
+void launch_wsum(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B,
+                 int N, int M, const Scratch& sc, bool x32, hipStream_t st) {
+    static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and MFMA kernel must tile rows alike");
+    static_assert(WsumShape<MODE, D>::kPart == MergeOp::kPartial, "partial formats differ");
+    constexpr int NQ = WsumShape<MODE, D>::kNQ;
+    unsigned chunk_grid = 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kMfmaRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
+    const long per_split = (long)B * N * MergeOp::kPartial * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * MergeOp::kPartial;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+
+    // pre-packed column records + q vectors behind the split partials (see launch_softmin_mfma_nw)
+    PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    PackedQ pq{nullptr, (long)B * M};
+    const size_t rec_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
+    auto plan_pre = [&](int ns) {
+        const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
+        if (!wsum_uses_x32<MODE>() || !x32 || !sc.prepack((double)B * N * M)) return false;
+        if (sc.bytes < part_bytes + rec_bytes + (size_t)NQ * B * M * sizeof(float)) return false;
+        pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+        pq.q = reinterpret_cast<float*>(static_cast<char*>(sc.ws) + part_bytes + rec_bytes);
+        if constexpr (wsum_uses_x32<MODE>()) {
+            if (n_ranges > 0) hipLaunchKernelGGL((wsum_pack_kernel<MODE, D, T, false>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk, pq);
+            else hipLaunchKernelGGL((wsum_pack_kernel<MODE, D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk, pq);
+        }
+        return true;
+    };
+
+    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD (workgroup_coords)
+        const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+        const int nx = !(wsum_uses_x32<MODE>() && x32) ? 8
+                       : sc.prepack((double)B * N * M) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit)
+                                                       : xcd_splits((long)gx * B, M, kFwdSlots, fit);
+        const long total = (long)gx * B * nx;
+        if (total < (1L << 31)) {
+            sp.n_splits = nx;
+            sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
+            const bool pre = plan_pre(nx);
+            launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp, pk, pq);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+            return;
+        }
+    }
+    const bool pre = plan_pre(sp.n_splits);
+    if (n_ranges > 0) {
+        launch_wsum_kernel<MODE, D, T, true>(x32, pre, dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp, pk, pq);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+    } else {
+        const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+        launch_wsum_kernel<MODE, D, T, false>(x32, pre, dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp, pk, pq);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+    }
+}
+
+template <int D, typename T>
+void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                             const Scratch& sc, bool x32, hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.h; w.fwd = prm.fwd; w.g = prm.g; w.out = nullptr; w.gx = prm.gx;
+    w.s2 = prm.s2; w.out_scale = prm.out_scale; w.gscale = 1.f; w.tscale = 1.f;
+    launch_wsum<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
+}
+
+template <int D, bool BWD, typename T>
+void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
+                      bool direct, bool mfma, int kind, const Scratch& sc, hipStream_t st) {
+    if (p == 1) { launch_softmin_r<D, 1, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st); return; }
+    if (direct) { launch_softmin_r<D, 2, true, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st); return; }
+    if (!mfma) { launch_softmin_r<D, 2, false, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st); return; }
+    if constexpr (BWD) {
+        launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, kind == FWD_X32, st);
+    } else {   // `if constexpr`: the gradient translation unit does not instantiate the forward kernels, and vice versa
+        if (kind == FWD_X32) launch_softmin_mfma<D, T, FWD_X32>(prm, rg, n_ranges, B, N, M, sc, st);
+        else if (kind == FWD_XDL16) launch_softmin_mfma<D, T, FWD_XDL16>(prm, rg, n_ranges, B, N, M, sc, st);
+        else launch_softmin_mfma<D, T, FWD_F32>(prm, rg, n_ranges, B, N, M, sc, st);
+    }
+}
+
+template <typename T>
+SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* h, float* out, float eps, int p,
+                                     const float* pot, const float* prev, float alpha, float beta) {
+    const float s2 = kLog2e / eps;
+    SoftminParams<T> prm;
+    prm.x = static_cast<const T*>(x);
+    prm.y = static_cast<const T*>(y);
+    prm.h = h;
+    prm.out = out;
+    prm.fwd = nullptr;
+    prm.g = nullptr;
+    prm.gx = nullptr;
+    prm.s2 = s2;
+    prm.t = (p == 1) ? s2 : std::sqrt(0.5f * s2);
+    prm.inv_t = 1.0f / prm.t;
+    prm.out_scale = -eps * kLn2;
+    prm.clamp2 = 1e-8f * prm.t * prm.t;
+    prm.pot = pot;
+    prm.prev = prev;
+    prm.pot_scale = 1.0f / eps;
+    prm.alpha = alpha;
+    prm.beta = beta;
+    return prm;
+}
+
+// glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
+template <int D, typename T>
+void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;
+    constexpr int NW = 4, kRows = NW * 32;
+    int maxN = 0, minM = m.M[0];
+    long row_blocks = 0;
+    for (int k = 0; k < m.count; ++k) {
+        maxN = m.N[k] > maxN ? m.N[k] : maxN;
+        minM = m.M[k] < minM ? m.M[k] : minM;
+        row_blocks += (long)B * ((m.N[k] + kRows - 1) / kRows);
+    }
+    const long per_split = (long)m.count * B * maxN * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = 0;   // per problem, set in the kernels
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    m.ws_stride = (long)sp.n_splits * B * maxN * 2;
+    const int gx = (maxN + kRows - 1) / kRows;
+    hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
+}
+
+template <typename T>
+int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
+                const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
+                int B, int N, int M, int D, float eps, float damping, int first, const Scratch& sc, hipStream_t st) {
+    // first = 0: averaged update;  1: initial potentials (no pot, no prev);  2: plain extrapolation (pot, no prev)
+    const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
+    auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
+        return make_softmin_params<T>(rows, cols, logw, out, eps, 2, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
+    };
+    SoftminMulti<T> m;
+    m.count = f_aa_out ? 4 : 2;
+    m.p[0] = one(x, y, b_log, g_ab, f_ba, f_ba_out); m.N[0] = N; m.M[0] = M;
+    m.p[1] = one(y, x, a_log, f_ba, g_ab, g_ab_out); m.N[1] = M; m.M[1] = N;
+    if (m.count == 4) {
+        m.p[2] = one(x, x, a_log, f_aa, f_aa, f_aa_out); m.N[2] = N; m.M[2] = N;
+        m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
+    } else {
+        m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+    }
+    if (D == 1) launch_iter4<1, T>(m, B, sc, st);
+    else if (D == 2) launch_iter4<2, T>(m, B, sc, st);
+    else launch_iter4<3, T>(m, B, sc, st);
+    return GLHIP_OK;
+}
+
+struct StepArgs {   // fused Sinkhorn half-step; all-default = plain soft-min
+    const float* pot = nullptr;
+    const float* prev = nullptr;
+    float alpha = 1.f, beta = 0.f;
+};
+
+template <bool BWD, typename T>
+int softmin_typed(const void* x, const void* y, const float* h, float* out, const float* fwd, const float* g,
+                  float* gx, int B, int N, int M, int D, float eps, int p, const Ranges& rg, int n_ranges,
+                  const Scratch& sc, int flags, hipStream_t st, const StepArgs& step = StepArgs()) {
+    const float s2 = kLog2e / eps;
+    const float out_scale = -eps * kLn2;
+    if (D <= 3) {
+        const bool direct = (flags & GLHIP_FLAG_DIRECT) != 0;
+        SoftminParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.h = h;
+        prm.out = out;
+        prm.fwd = fwd;
+        prm.g = g;
+        prm.gx = gx;
+        prm.s2 = s2;
+        prm.t = (p == 1) ? s2 : std::sqrt(0.5f * s2);
+        prm.inv_t = 1.0f / prm.t;
+        prm.out_scale = out_scale;
+        prm.clamp2 = 1e-8f * prm.t * prm.t;
+        prm.pot = step.pot;
+        prm.prev = step.prev;
+        prm.pot_scale = 1.0f / eps;
+        prm.alpha = step.alpha;
+        prm.beta = step.beta;
+        const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
+        const int xdl = (flags & GLHIP_FLAG_F32_MFMA) ? FWD_F32 : (flags & GLHIP_FLAG_XDL16) ? FWD_XDL16 : FWD_X32;
+        if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
+        else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
+        else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
+    } else {
+        if (step.pot || step.prev || step.alpha != 1.f)
+            return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: D=%d > 3 has no fused kernel (use glhip_softmin_fwd)", D);
+        if (BWD && D > kGenericMaxGradD)
+            return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
+                        D, kGenericMaxGradD);
+        GenericParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.s = h;
+        prm.out = out;
+        prm.fwd = fwd;
+        prm.g = g;
+        prm.gx = gx;
+        prm.dscale = (p == 1) ? s2 : 0.5f * s2;
+        prm.out_scale = out_scale;
+        prm.gscale = 1.f;
+        prm.clamp2 = 1e-8f;
+        const bool sp = n_ranges > 0;
+        dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
+#define GL_LAUNCH(MODE, SP) \
+    hipLaunchKernelGGL((generic_kernel<MODE, BWD, SP, T>), grid, dim3(kBlock), 0, st, prm, rg, N, M, D)
+        if (p == 2) { if (sp) GL_LAUNCH(GM_SOFTMIN_P2, true); else GL_LAUNCH(GM_SOFTMIN_P2, false); }
+        else        { if (sp) GL_LAUNCH(GM_SOFTMIN_P1, true); else GL_LAUNCH(GM_SOFTMIN_P1, false); }
+#undef GL_LAUNCH
+    }
+    return GLHIP_OK;
+}
+
+// ---- kernel products ---------------------------------------------------------------------------------
+
+template <int KIND, int D, bool BWD, typename T>
+void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
+                   hipStream_t st) {
+    if (use_two_rows(B, N, n_ranges, sc))
+        launch_mapreduce<ConvOp<KIND, D, 2, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+    else
+        launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
+}
+
+template <int KIND, bool BWD, typename T>
+void launch_conv_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int D,
+                   const Scratch& sc, hipStream_t st) {
+    if (D == 1) launch_conv_r<KIND, 1, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (D == 2) launch_conv_r<KIND, 2, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+    else launch_conv_r<KIND, 3, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
+}
+
+template <int D, bool BWD, typename T>
+void launch_gauss_mfma(const ConvParams<T>& prm, float blur, const Ranges& rg, int n_ranges, int B, int N, int M,
+                       const Scratch& sc, bool x32, hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.v; w.fwd = nullptr; w.g = prm.g; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = kLog2e / (blur * blur); w.out_scale = 1.f; w.gscale = -1.0f / (blur * blur); w.tscale = prm.t;
+    if constexpr (BWD) launch_wsum<WS_GAUSS_BWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, true>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
+    else launch_wsum<WS_GAUSS_FWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, false>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
+}
+
+// gaussian product + its row gradient in one pass (WS_GAUSS_FWDGRAD)
+template <int D, typename T>
+void launch_gauss_fwdgrad(const ConvParams<T>& prm, float blur, const Ranges& rg, int n_ranges, int B, int N, int M,
+                          const Scratch& sc, hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.v; w.fwd = nullptr; w.g = nullptr; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = kLog2e / (blur * blur); w.out_scale = 1.f; w.gscale = -1.0f / (blur * blur); w.tscale = prm.t;
+    launch_wsum<WS_GAUSS_FWDGRAD, D, T, GaussFwdGradMerge<D, T>>(w, prm, rg, n_ranges, B, N, M, sc, false, st);
+}
+
+template <bool BWD, typename T>
+int conv_typed(int kind, const void* x, const void* y, const float* v, float* out, const float* g, float* gx,
+               int B, int N, int M, int D, float blur, const Ranges& rg, int n_ranges, const Scratch& sc,
+               int flags, hipStream_t st) {
+    if (D <= 3) {
+        ConvParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.v = v;
+        prm.out = out;
+        prm.g = g;
+        prm.gx = gx;
+        if (kind == GLHIP_GAUSSIAN) {
+            prm.t = std::sqrt(0.5f * kLog2e) / blur;
+            prm.gscale = -1.0f / (prm.t * blur * blur);
+            prm.clamp2 = 0.f;
+            if ((flags & GLHIP_FLAG_NO_MFMA) == 0) {
+                const bool x32 = (flags & GLHIP_FLAG_XDL16) == 0;
+                if (D == 1) launch_gauss_mfma<1, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
+                else if (D == 2) launch_gauss_mfma<2, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
+                else launch_gauss_mfma<3, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
+            } else {
+                launch_conv_d<GLHIP_GAUSSIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+            }
+        } else if (kind == GLHIP_LAPLACIAN) {
+            prm.t = kLog2e / blur;
+            prm.gscale = -1.0f / blur;
+            prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
+            launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+        } else {
+            prm.t = 1.0f;
+            prm.gscale = -1.0f;
+            prm.clamp2 = 1e-8f;
+            launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+        }
+    } else {
+        if (BWD && D > kGenericMaxGradD)
+            return fail(GLHIP_EUNSUPPORTED, "kernel_conv_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
+                        D, kGenericMaxGradD);
+        GenericParams<T> prm;
+        prm.x = static_cast<const T*>(x);
+        prm.y = static_cast<const T*>(y);
+        prm.s = v;
+        prm.out = out;
+        prm.fwd = nullptr;
+        prm.g = g;
+        prm.gx = gx;
+        prm.out_scale = 1.f;
+        prm.clamp2 = 1e-8f;
+        const bool sp = n_ranges > 0;
+        dim3 grid(sp ? n_ranges : (N + kBlock - 1) / kBlock, sp ? 1 : B, 1);
+#define GL_LAUNCH(MODE, SP) \
+    hipLaunchKernelGGL((generic_kernel<MODE, BWD, SP, T>), grid, dim3(kBlock), 0, st, prm, rg, N, M, D)
+        if (kind == GLHIP_GAUSSIAN) {
+            prm.dscale = 0.5f * kLog2e / (blur * blur);
+            prm.gscale = -1.0f / (blur * blur);
+            if (sp) GL_LAUNCH(GM_GAUSS, true); else GL_LAUNCH(GM_GAUSS, false);
+        } else if (kind == GLHIP_LAPLACIAN) {
+            prm.dscale = kLog2e / blur;
+            prm.gscale = -1.0f / blur;
+            prm.clamp2 = 1e-8f * blur * blur;
+            if (sp) GL_LAUNCH(GM_LAPLACE, true); else GL_LAUNCH(GM_LAPLACE, false);
+        } else {
+            prm.dscale = 1.f;
+            prm.gscale = -1.0f;
+            if (sp) GL_LAUNCH(GM_ENERGY, true); else GL_LAUNCH(GM_ENERGY, false);
+        }
+#undef GL_LAUNCH
+    }
+    return GLHIP_OK;
+}
+
+}  // namespace

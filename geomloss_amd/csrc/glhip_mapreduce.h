@@ -103,7 +103,7 @@ __device__ __forceinline__ void column_interval(const Ranges& rg, int M, int q, 
 // `rows` rows (the row tile of the kernel that follows) with a block-wide prefix sum over the clusters, so that the grid of
 // the reduction is one workgroup per chunk: chunks[0] = T, chunks[1 + 3c ...] = (row block, first row, end row).  The host
 // only knows the bound T <= n_ranges + N / rows and launches that many workgroups; the surplus exits at once.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int rows, int32_t* __restrict__ chunks, int capacity) {
     __shared__ int scan[1024];
     __shared__ int carry;
