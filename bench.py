@@ -359,6 +359,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="global batch of the sharded workload (N > 1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (kernels, cpu_baseline, wall-clocks)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU dry run)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 (batch-sharded) leg even with one rank: exercises process-group init + the RCCL all-reduce on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true",
                     help="dry run of the N>1 path on a 1-GPU box: every rank uses cuda:0 (only with --backend gloo)")
     args = ap.parse_args()
@@ -377,7 +379,7 @@ def main():
     from geomloss_amd import hip
     hip.load_library()   # raises if the HIP extension is missing: there is no fallback to time
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         run_headline(args, dev)
         return
     import torch.distributed as dist

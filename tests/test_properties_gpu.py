@@ -212,3 +212,22 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(cuda):
     ref = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)(x, y).sum().item()
     assert abs(rec["loss_sum"] - ref) <= 1e-6 * abs(ref)
     assert abs(rec["config"]["pairs_per_step"] - 6 * 40 * 4096.0**2) < 1
+
+
+def test_bench_sharded_path_on_rccl_single_rank(cuda):
+    """The same leg over the real backend (`nccl` = RCCL): one rank, so that process-group creation, the barrier and the scalar
+    all-reduce run through RCCL on this GPU (two ranks cannot share a device under RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--backend", "nccl"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "nccl" in rec["config"]["parallelism"]
