@@ -148,6 +148,7 @@ def hot_path_kernels(dev, n=1_000_000):
     add("softmin_bwd_x_p2", lambda: hip.softmin_bwd_x_raw(x, y, h, out, g, eps, 2))
     add("gaussian_product", lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, x, y, v, blur))
     add("gaussian_gradient", lambda: hip.kernel_conv_bwd_x_raw(hip.GAUSSIAN, x, y, v, g, blur))
+    add("gaussian_product_and_gradient", lambda: hip.kernel_conv_fwd_grad_raw(hip.GAUSSIAN, x, y, v, blur))
     add("softmin_fwd_p1", lambda: hip.softmin_fwd_raw(x, y, h, 0.05, 1), reps=2)
     add("laplacian_product", lambda: hip.kernel_conv_fwd_raw(hip.LAPLACIAN, x, y, v, blur), reps=2)
     add("energy_product", lambda: hip.kernel_conv_fwd_raw(hip.ENERGY, x, y, v, blur), reps=2)
