@@ -137,6 +137,18 @@ def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p
     """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``).  ``kind``: "dual_slack"
     (f_i + g_j > C_ij - thr, sinkhorn_samples.py:512-514) or "within" (|c_i - c_j|^2 <= thr, kernel_samples.py:244-252)."""
     from . import hip
+    if rows.shape[0] * cols.shape[0] > 1 << 25:
+        # the worst-case interval buffers (Cr * Cc / 2 entries, twice) stop being "small" from ~6e3 x 6e3 clusters on: build the
+        # mask like the reference does (dense Cr x Cc, torch) and go through from_matrix
+        with torch.no_grad():
+            r, c = rows.detach().float(), cols.detach().float()
+            d2 = ((r * r).sum(1)[:, None] + (c * c).sum(1)[None, :] - 2 * r @ c.t()).clamp_min(0)
+            if kind == "within":
+                keep = d2 <= thr
+            else:
+                C = d2 / 2 if p == 2 else d2.clamp_min(1e-8).sqrt()
+                keep = f.detach().float().view(-1, 1) + g.detach().float().view(1, -1) > C - thr
+            return from_matrix(ranges_rows, ranges_cols, keep)
     code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
     f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
     return hip.block_ranges_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),

@@ -142,3 +142,19 @@ def test_multiscale_losses_are_the_same_on_both_clustering_paths(cuda, monkeypat
     assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[2] - b[2]) <= 2e-6 * abs(b[2])
     assert (a[1] - b[1]).abs().max() <= 1e-5 * b[1].abs().max() and (a[3] - b[3]).abs().max() <= 1e-5 * b[3].abs().max()
     assert (a[4] - b[4]).abs().max() <= 1e-6 and (a[5] - b[5]).abs().max() <= 1e-6
+
+
+def test_multiscale_loss_is_bitwise_reproducible(cuda):
+    """Same inputs, same bits: no floating-point atomics anywhere between the clouds and the loss (deterministic centroids,
+    fixed-order block-sparse reductions)."""
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.rand(150_000, 3, generator=g).to(cuda), torch.rand(150_000, 3, generator=g).to(cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")
+    vals = []
+    for _ in range(3):
+        xg = x.clone().requires_grad_(True)
+        v = L(xg, y)
+        (gx,) = torch.autograd.grad(v, [xg])
+        vals.append((v.item(), gx))
+    assert vals[0][0] == vals[1][0] == vals[2][0]
+    assert torch.equal(vals[0][1], vals[1][1]) and torch.equal(vals[0][1], vals[2][1])
