@@ -142,7 +142,7 @@ class _HipSoftmin:
         if self.multiscale and C_xy[4] is not None:     # truncated fine level: block-sparse launches
             return None
         B = 1 if x.dim() == 2 else x.shape[0]
-        if float(B) * x.shape[-2] * y.shape[-2] >= 5e8:
+        if float(B) * x.shape[-2] * y.shape[-2] >= _ITER4_MAX_PAIRS:
             return None
         plan = self._plan
         if plan is None or plan[0] is not x or plan[1] is not a_log or plan[2] is not b_log or plan[3] != debias:
@@ -169,6 +169,8 @@ class _HipSoftmin:
 # kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
 _fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
+# ... up to this many pairs per soft-min; bigger problems fill the GPU with one soft-min per launch (pre-packed columns, XCD grids)
+_ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "5e8"))
 _graphs = hip.GraphCache()
 
 
