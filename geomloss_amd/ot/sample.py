@@ -127,9 +127,7 @@ def _to_gpu(v, dev):
 
 def stable_log(a):
     """log(a) with log(0) = -100000 (``_backends/torch.py:24-28``)."""
-    a_log = a.log()
-    a_log[a <= 0] = -100000
-    return a_log
+    return torch.where(a > 0, a.log(), torch.full_like(a, -100000.0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -64,9 +64,7 @@ def upsample(I):
 
 def log_dens(α):
     """log of a density, -10000 where it vanishes (``utils.py:104-107``)."""
-    α_log = α.log()
-    α_log[α <= 0] = -10000.0
-    return α_log
+    return torch.where(α > 0, α.log(), torch.full_like(α, -10000.0))     # no boolean-mask indexing (host round trip)
 
 
 def C_transform(G, tau=1, p=2):
