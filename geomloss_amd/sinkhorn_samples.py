@@ -170,7 +170,7 @@ class _HipSoftmin:
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
 _fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
 # ... up to this many pairs per soft-min; bigger problems fill the GPU with one soft-min per launch (pre-packed columns, XCD grids)
-_ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "5e8"))
+_ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "4e9"))   # measured: B x 4096^2 with B = 32..128 and N = 3e4 gain 5-13 %, 7e4+ lose
 _graphs = hip.GraphCache()
 
 
