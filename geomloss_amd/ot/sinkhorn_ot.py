@@ -143,7 +143,7 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
         f_aa, g_bb = (init(x, x, a, a), init(y, y, b, b)) if debias else (None, None)
 
         plan = None
-        fusable = x.shape[1] <= 3 and float(x.shape[0]) * y.shape[0] < 5e8
+        fusable = x.shape[1] <= 3 and float(x.shape[0]) * y.shape[0] < 4e9
         if fusable:   # one launch per iteration (glhip_sinkhorn_iter4)
             plan = hip.Iter4Plan(x, y, log_a, log_b, debias)
 
