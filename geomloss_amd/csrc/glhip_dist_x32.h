@@ -1,0 +1,221 @@
+// glhip_dist_x32.h — the reductions whose cost is a DISTANCE (not a squared distance): soft-min with p = 1, laplacian and
+// energy kernel products — with the squared distance formed on the matrix cores (D <= 3).
+//
+// The VALU operators (SoftminFwdOp<.,1,true>, ConvOp<LAPLACIAN|ENERGY>) evaluate |x - y|^2 on explicit differences: 3 sub +
+// 3 fma per pair before the square root — 13.3 / 10.1 / 9.1 VALU instructions per pair in all (profiles/r02_kernels_pmc.txt).
+// Here the scaled squared distance of a 32 x 32 block of pairs comes out of the same chained pair of v_mfma_f32_32x32x16_bf16 as
+// the exponent of the p = 2 soft-min (glhip_softmin_x32.h; every fp32 operand = 3 exact bf16 pieces):
+//     d2_ij = |xs_i|^2 + |ys_j|^2 - 2 xs_i . ys_j      xs = t (x - c), ys = t (y - c)
+//       K blocks d < D : y side [y1,y2,y1,y3,y1,y2,y3,y2]       x side pieces of -2 xs_d
+//       K block 3      : y side [N1,N2,N3,1,1,1,0,0] (|ys|^2)    x side [1,1,1,n1,n2,n3,0,0] (|xs|^2)
+// and a third MFMA broadcasts the per-column scalar to the lanes that hold the column's 16 rows:
+//       K block 4      : y side [S1,S2,S3,1,1,1,0,0]             x side [1,1,1,m1,m2,m3,0,0]   (soft-min: S = H_j, m = -running max;
+//                                                                                               kernel products: S = v_j, m = 0)
+// What is left for the VALU per pair: max (the clamp of utils.py:61), v_sqrt_f32, and
+//     soft-min p = 1 : sub, v_exp_f32, add          laplacian : v_exp_f32 (negated input), fma          energy : fma
+// i.e. 5 / 4 / 3 instructions instead of 13 / 10 / 9.
+//
+// ACCURACY.  d2 carries the absolute error of the expanded form, ~2^-23 t^2 R^2 with R the distance of the two points from the
+// centre c, so d = sqrt(d2) is off by ~2^-24 t R^2 / d: harmless for far pairs (R ~ d) but not for near pairs seen from a far
+// centre.  This kernel is therefore only used on BLOCK-SPARSE launches whose row blocks are spatially compact (the voxel clusters
+// of the multiscale backends, or the voxel sort the Python drivers apply to large dense launches): c is the first row of the
+// workgroup's row chunk, near pairs then have R <~ cluster diameter, and the error of a potential stays ~2^-24 (rho + d)^2 / d.
+// The caller opts in with GLHIP_FLAG_MFMA_DIST; everything else stays on the direct-difference operators.
+#pragma once
+
+#include "glhip_kconv_ops.h"
+#include "glhip_softmin_x32.h"
+
+namespace glhip {
+
+enum DistMode { DM_SOFTMIN_P1 = 0, DM_LAPLACIAN = 1, DM_ENERGY = 2 };
+
+template <typename T>
+struct DistParams {
+    const T* x;          // (N,D)
+    const T* y;          // (M,D)
+    const float* s;      // (M): dual vector h (soft-min) or weights v (kernel products)
+    const float* pot;    // soft-min, fused half-step: h_j := s_j + pot_scale * pot_j (or NULL)
+    const float* prev;   // soft-min, fused half-step: out_i := alpha * f_i + beta * prev_i (or NULL)
+    float* out;          // (N)
+    float t;             // coordinate scale: log2(e)/eps (p = 1), log2(e)/blur (laplacian), 1 (energy)
+    float clamp2;        // 1e-8 t^2
+    float out_scale;     // soft-min: -eps ln 2
+    float pot_scale, alpha, beta;
+};
+
+constexpr int kDistRec = 5;                 // 16-byte records per column
+constexpr int kDistTile = 512;              // columns per LDS tile: 512 x 5 x 16 B = 40 KiB
+
+// reduction of one 32 x 32 block: d2 (scaled squared distances), sb (per-column scalar, minus the running max for the soft-min)
+template <int MODE>
+__device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, float clamp2) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float dist = fast_sqrt(fmaxf(d2[k], clamp2));
+        if (MODE == DM_SOFTMIN_P1) acc[k & 3] += fast_exp2(sb[k] - dist);
+        else if (MODE == DM_LAPLACIAN) acc[k & 3] = __builtin_fmaf(fast_exp2(-dist), sb[k], acc[k & 3]);
+        else acc[k & 3] = __builtin_fmaf(-dist, sb[k], acc[k & 3]);
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <int MODE, int D, typename T, int NW>
+__global__ void __launch_bounds__(NW * 64)
+dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    constexpr int kRowsPerBlock = NW * 32;
+    constexpr int kThreads = NW * 64;
+    __shared__ uint4 tile[kDistTile * kDistRec];      // [column group of 32][K block 0..4][column]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.z;
+    const int ns = sp.n_splits;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int rec0 = half * 32 + l31;     // K block `half` of column l31 inside a group (+64: K block half + 2)
+
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<true>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, blockIdx.x);
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint4 kOnes = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // [1,1,1,0,...]
+    const uint4 kZero = uint4{0u, 0u, 0u, 0u};
+
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
+        float centre[D];
+        load_point<D, T>(prm.x, row0, centre);
+
+        const int wave_row0 = row0 + wave * 32;
+        const bool wave_active = wave_row0 < row_end;
+        uint4 Xlo, Xhi, Xs;
+        {
+            const int i = min(wave_row0 + l31, row_end - 1);
+            float xi[D];
+            load_point<D, T>(prm.x, i, xi);
+            float a[3] = {0.f, 0.f, 0.f}, n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float xs = (xi[d] - centre[d]) * prm.t;
+                n2 = __builtin_fmaf(xs, xs, n2);
+                a[d] = -2.f * xs;
+            }
+            const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : kZero, p2 = (D > 2) ? pack_a(a[2]) : kZero;
+            Xlo = half ? p1 : p0;
+            Xhi = half ? pack_negmax(-n2) : p2;            // block 3 carries + |xs|^2
+            Xs = half ? kZero : kOnes;                     // block 4: the scalar itself (soft-min: rewritten with the running max)
+        }
+        float m = kMinusHuge, ssum = 0.f;                  // soft-min: lazy running max and sum;  products: ssum only
+        bool first_group = true;
+
+        for (int q = q_begin + split; q < q_end; q += ns) {
+            const int js = rg.redranges_j[2 * q], je = rg.redranges_j[2 * q + 1];
+            for (int j0 = js; j0 < je; j0 += kDistTile) {
+                const int n = min(kDistTile, je - j0);
+                const int npad = (n + 31) & ~31;
+                __syncthreads();
+                for (int t = tid; t < npad; t += kThreads) {
+                    float ys[3] = {0.f, 0.f, 0.f}, n2 = 0.f, sj = (MODE == DM_SOFTMIN_P1) ? kNegBig : 0.f;
+                    if (t < n) {
+                        float yj[D];
+                        load_point<D, T>(prm.y, j0 + t, yj);
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            ys[d] = (yj[d] - centre[d]) * prm.t;
+                            n2 = __builtin_fmaf(ys[d], ys[d], n2);
+                        }
+                        sj = prm.s[j0 + t];
+                        if (MODE == DM_SOFTMIN_P1) {
+                            if (prm.pot) sj = __builtin_fmaf(prm.pot[j0 + t], prm.pot_scale, sj);
+                            sj *= kLog2e;
+                        }
+                    }
+                    uint4* base = &tile[(t >> 5) * (32 * kDistRec) + (t & 31)];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(ys[d]) : kZero;
+                    base[3 * 32] = pack_h1(n2);
+                    base[4 * 32] = pack_h1(sj);
+                }
+                __syncthreads();
+                if (!wave_active) continue;
+
+                const int nG = npad / 32;
+                int G0 = 0;
+                if (MODE == DM_SOFTMIN_P1 && first_group) {      // exact maximum over the first 32 columns
+                    const uint4* g = &tile[0];
+                    f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
+                    d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                    const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
+                    float um = kMinusHuge;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) um = fmaxf(um, sb[k] - fast_sqrt(fmaxf(d2[k], prm.clamp2)));
+                    um = fmaxf(um, __shfl_xor(um, 32, 64));
+                    m = um;
+                    if (!half) Xs = pack_negmax(m);
+                    ssum = block_sum<MODE>(d2, mfma_x32(half ? kZero : g[128 + l31], Xs, zero16), prm.clamp2);
+                    first_group = false;
+                    G0 = 1;
+                }
+                float stmp = 0.f;
+                for (int G = G0; G < nG; ++G) {
+                    const uint4* g = &tile[G * (32 * kDistRec)];
+                    f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
+                    d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                    const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
+                    stmp += block_sum<MODE>(d2, sb, prm.clamp2);
+                }
+                if (MODE == DM_SOFTMIN_P1 && __any(!(stmp < kSumThr))) {
+                    // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
+                    const uint4 plain = half ? kZero : kOnes;
+                    for (int G = G0; G < nG; ++G) {
+                        const uint4* g = &tile[G * (32 * kDistRec)];
+                        f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
+                        d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                        const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], plain, zero16);
+                        float u[16], um = kMinusHuge;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            u[k] = sb[k] - fast_sqrt(fmaxf(d2[k], prm.clamp2));
+                            um = fmaxf(um, u[k]);
+                        }
+                        um = fmaxf(um, __shfl_xor(um, 32, 64));
+                        const float mnew = fmaxf(m, um);
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) s2 += fast_exp2(u[k] - mnew);
+                        ssum = ssum * fast_exp2(m - mnew) + s2;
+                        m = mnew;
+                    }
+                    if (!half) Xs = pack_negmax(m);
+                } else {
+                    ssum += stmp;
+                }
+            }
+        }
+
+        if (wave_active) {
+            const float s = ssum + __shfl_xor(ssum, 32, 64);     // the two halves hold the two 16-column halves of every block
+            const int i = wave_row0 + l31;
+            if (half == 0 && i < row_end) {
+                if (MODE == DM_SOFTMIN_P1) {
+                    if (ns == 1) {
+                        float f = prm.alpha * (prm.out_scale * (m + fast_log2(s)));
+                        if (prm.prev) f = __builtin_fmaf(prm.beta, prm.prev[i], f);
+                        prm.out[i] = f;
+                    } else {
+                        float* dst = sp.workspace + split * sp.split_stride + (long)i * 2;
+                        dst[0] = m;
+                        dst[1] = s;
+                    }
+                } else {
+                    if (ns == 1) prm.out[i] = s;
+                    else sp.workspace[split * sp.split_stride + i] = s;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace glhip

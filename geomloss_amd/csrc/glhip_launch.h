@@ -16,6 +16,7 @@
 #include "glhip_softmin_xdl.h"
 #include "glhip_softmin_x32.h"
 #include "glhip_wsum_x32.h"
+#include "glhip_dist_x32.h"
 
 using namespace glhip;
 
@@ -291,6 +292,32 @@ void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int 
     launch_wsum<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
 }
 
+// p = 1 soft-min / laplacian / energy with the squared distance on the matrix cores (glhip_dist_x32.h): block-sparse launches whose
+// row blocks are spatially compact, on the caller's word (GLHIP_FLAG_MFMA_DIST).  Row chunks, column splits and the merge as above.
+constexpr int kDistNW = 8;
+
+template <int MODE, int D, typename T, class MergeOp>
+void launch_dist(const DistParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int N, int M,
+                 const Scratch& sc, hipStream_t st) {
+    unsigned chunk_grid = 0;
+    const Ranges rgc = with_row_chunks(rg, n_ranges, N, kDistNW * 32, sc.cb, st, chunk_grid);
+    const long per_split = (long)N * MergeOp::kPartial * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(n_ranges, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)N * MergeOp::kPartial;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    hipLaunchKernelGGL((dist_x32_kernel<MODE, D, T, kDistNW>), dim3(chunk_grid, 1, sp.n_splits), dim3(kDistNW * 64), 0, st, prm, rgc, N, M, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+}
+
+inline bool use_mfma_dist(int flags, int n_ranges, int B, int D) {
+    return (flags & GLHIP_FLAG_MFMA_DIST) != 0 && n_ranges > 0 && B == 1 && D <= 3;
+}
+
 template <int D, bool BWD, typename T>
 void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int p,
                       bool direct, bool mfma, int kind, const Scratch& sc, hipStream_t st) {
@@ -417,6 +444,15 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.beta = step.beta;
         const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
         const int xdl = (flags & GLHIP_FLAG_F32_MFMA) ? FWD_F32 : (flags & GLHIP_FLAG_XDL16) ? FWD_XDL16 : FWD_X32;
+        if constexpr (!BWD) {
+            if (p == 1 && use_mfma_dist(flags, n_ranges, B, D)) {
+                DistParams<T> dp{prm.x, prm.y, h, step.pot, step.prev, out, s2, 1e-8f * s2 * s2, out_scale, 1.0f / eps, step.alpha, step.beta};
+                if (D == 1) launch_dist<DM_SOFTMIN_P1, 1, T, SoftminFwdOp<1, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                else if (D == 2) launch_dist<DM_SOFTMIN_P1, 2, T, SoftminFwdOp<2, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                else launch_dist<DM_SOFTMIN_P1, 3, T, SoftminFwdOp<3, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                return GLHIP_OK;
+            }
+        }
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
@@ -516,11 +552,29 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.t = kLog2e / blur;
             prm.gscale = -1.0f / blur;
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
+            if constexpr (!BWD) {
+                if (use_mfma_dist(flags, n_ranges, B, D)) {
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f};
+                    if (D == 1) launch_dist<DM_LAPLACIAN, 1, T, ConvOp<GLHIP_LAPLACIAN, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    else if (D == 2) launch_dist<DM_LAPLACIAN, 2, T, ConvOp<GLHIP_LAPLACIAN, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    else launch_dist<DM_LAPLACIAN, 3, T, ConvOp<GLHIP_LAPLACIAN, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    return GLHIP_OK;
+                }
+            }
             launch_conv_d<GLHIP_LAPLACIAN, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         } else {
             prm.t = 1.0f;
             prm.gscale = -1.0f;
             prm.clamp2 = 1e-8f;
+            if constexpr (!BWD) {
+                if (use_mfma_dist(flags, n_ranges, B, D)) {
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f};
+                    if (D == 1) launch_dist<DM_ENERGY, 1, T, ConvOp<GLHIP_ENERGY, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    else if (D == 2) launch_dist<DM_ENERGY, 2, T, ConvOp<GLHIP_ENERGY, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    else launch_dist<DM_ENERGY, 3, T, ConvOp<GLHIP_ENERGY, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    return GLHIP_OK;
+                }
+            }
             launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         }
     } else {

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
 GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
-FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK = 1, 2, 4, 8, 16, 32
+FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/glhip.h declares, with its ctypes signature
 _c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -350,6 +350,72 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
 
 
 # ----------------------------------------------------------------------------------------------
+#  distance-type reductions on the matrix cores (GLHIP_FLAG_MFMA_DIST): compact row blocks for dense launches
+# ----------------------------------------------------------------------------------------------
+
+# p = 1 soft-min / laplacian / energy: large dense launches are voxel-sorted first, so that every row block of the launch is
+# spatially compact — the condition under which the squared distance may come from the MFMA (glhip_dist_x32.h)
+_dist_on_mfma = os.environ.get("GEOMLOSS_HIP_MFMA_DIST", "1") != "0"
+_DIST_MIN_ROWS, _DIST_MIN_PAIRS, _DIST_ROWS_PER_VOXEL, _DIST_COL_CHUNKS = 65536, 5e8, 512, 8
+
+
+def set_distance_on_mfma(enabled):
+    global _dist_on_mfma
+    _dist_on_mfma = bool(enabled)
+
+
+class _CompactRows:
+    """Voxel-sorted copy of a cloud + a block-sparse pattern "every row block x all columns" (in a few column chunks, so that
+    the column splits of the launch have something to split)."""
+
+    def __init__(self, xb, M):
+        x = xb[0]
+        N, D = x.shape
+        xf = x.float()
+        extent = (xf.amax(0) - xf.amin(0)).clamp_min(1e-12)
+        voxel = float((extent.prod() * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / D))        # ~512 rows per occupied voxel
+        self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, voxel)
+        self.x = xs.unsqueeze(0)
+        C = ranges.shape[0]
+        nchunk = _DIST_COL_CHUNKS
+        step = ((M + nchunk - 1) // nchunk + 31) // 32 * 32
+        starts = torch.arange(nchunk, device=x.device, dtype=torch.int32) * step
+        cols = torch.stack((starts.clamp_max(M), (starts + step).clamp_max(M)), 1)      # (nchunk, 2)
+        red = cols.repeat(C, 1).contiguous()
+        slices = (torch.arange(1, C + 1, device=x.device, dtype=torch.int32) * nchunk).contiguous()
+        self.ranges = BlockRanges(ranges.contiguous(), slices, red, None, None, None)
+
+    def unsort(self, out_sorted):
+        """(1, N, ...) in sorted row order -> original order."""
+        out = torch.empty_like(out_sorted)
+        out[0, self.perm.long()] = out_sorted[0]
+        return out
+
+
+_plan_cache = []     # [(weakref to the row tensor, its version, M, plan)]: the Sinkhorn loop reduces over the same clouds ~40 times
+
+
+def _compact_rows(xb, yb, ranges, flags, key=None):
+    """A :class:`_CompactRows` plan when a dense distance-type launch is big enough to be worth the sort, else None.
+    ``key``: the caller's tensor the rows come from — plans are remembered per (tensor, version, M) for a few tensors."""
+    import weakref
+    B, N, D = xb.shape
+    M = yb.shape[1]
+    if (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS
+            or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
+        return None
+    if key is not None:
+        for ref, version, m, plan in _plan_cache:
+            if ref() is key and version == key._version and m == M:
+                return plan
+    plan = _CompactRows(xb, M)
+    if key is not None:
+        _plan_cache.append((weakref.ref(key), key._version, M, plan))
+        del _plan_cache[:-4]
+    return plan
+
+
+# ----------------------------------------------------------------------------------------------
 #  autograd functions
 # ----------------------------------------------------------------------------------------------
 
@@ -361,7 +427,13 @@ class _Softmin(torch.autograd.Function):
         xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
+        plan = _compact_rows(xb, yb, ranges, flags, key=x) if p == 1 else None
+        if plan is not None:       # large dense p = 1 launch: voxel-sorted rows, squared distances on the matrix cores
+            out = plan.unsort(softmin_fwd_raw(plan.x, yb, hb, eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
+        else:
+            if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+                flags |= FLAG_MFMA_DIST            # multiscale: the row blocks are voxel clusters already
+            out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
         ctx.save_for_backward(xb, yb, hb, out)
         ctx.cfg = (eps, p, ranges, flags, x.shape, x.dtype)
         return out if batched else out.view(-1)
@@ -528,7 +600,15 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     B = xb.shape[0]
     pt = None if pot is None else _f32(pot).reshape(B, -1)
     pv = None if prev is None else _f32(prev).reshape(B, -1)
-    out = sinkhorn_step_raw(xb, yb, lw, pt, pv, eps, damping, p, ranges, int(flags) | ENV_FLAGS)
+    flags = int(flags) | ENV_FLAGS
+    plan = _compact_rows(xb, yb, ranges, flags, key=x) if p == 1 else None
+    if plan is not None:           # large dense p = 1 launch: voxel-sorted rows (plan cached across the iterations of the loop)
+        pvs = None if pv is None else pv[:, plan.perm.long()].contiguous()
+        out = plan.unsort(sinkhorn_step_raw(plan.x, yb, lw, pt, pvs, eps, damping, p, plan.ranges, flags | FLAG_MFMA_DIST))
+    else:
+        if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+            flags |= FLAG_MFMA_DIST
+        out = sinkhorn_step_raw(xb, yb, lw, pt, pv, eps, damping, p, ranges, flags)
     return out if batched else out.view(-1)
 
 
@@ -544,10 +624,16 @@ class _KernelConv(torch.autograd.Function):
         # accumulator of the gradient kernel is the product itself.  The backward pass is then elementwise.
         fused = (_fuse_kernel_grad and kind == GAUSSIAN and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
                  and not (flags & FLAG_NO_MFMA))
+        plan = _compact_rows(xb, yb, ranges, flags, key=x) if kind in (LAPLACIAN, ENERGY) else None
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
+        elif plan is not None:     # large dense laplacian / energy product: voxel-sorted rows, distances from the matrix cores
+            out, unit = plan.unsort(kernel_conv_fwd_raw(kind, plan.x, yb, vb, blur, plan.ranges, flags | FLAG_MFMA_DIST)), None
         else:
-            out, unit = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, flags), None
+            fl = flags
+            if kind in (LAPLACIAN, ENERGY) and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+                fl |= FLAG_MFMA_DIST               # multiscale: the row blocks are voxel clusters already
+            out, unit = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, fl), None
         ctx.unit = unit
         ctx.save_for_backward(xb, yb, vb)
         ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)

@@ -63,6 +63,10 @@ extern "C" {
 #define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split */
 #define GLHIP_FLAG_XDL16 16   /* p=2 softmin forward / gaussian product: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 */
 #define GLHIP_FLAG_PREPACK 32 /* pre-pack the columns whatever the launch size (default: launches of >= 5e8 pairs); needs workspace */
+#define GLHIP_FLAG_MFMA_DIST 64 /* p = 1 soft-min forward / laplacian / energy product, block-sparse launches, D <= 3: squared distances on
+                                 the matrix cores, centred on each row block (glhip_dist_x32.h).  2-3x fewer VALU instructions; accurate
+                                 (~2^-24 (rho + d)^2 / d on a potential, rho = row-block diameter) when row blocks are spatially compact:
+                                 the caller's responsibility (voxel clusters of the multiscale backends, voxel-sorted dense clouds). */
 
 /* error codes */
 #define GLHIP_OK 0

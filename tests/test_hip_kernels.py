@@ -471,6 +471,92 @@ def test_hard_c_transform_vs_numpy(cuda, N, M, D, B, p):
         assert np.abs(outs[live] - refs[live]).max() < 3e-6 * max(1.0, np.abs(refs[live]).max())
 
 
+def _clustered(seed, N, M, D, dev, voxel):
+    """Two clouds sorted by voxel cluster + the block-sparse pattern of a keep-mask on their centroids."""
+    from geomloss_amd import cluster
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.rand(N, D, generator=g).to(dev), torch.rand(M, D, generator=g).to(dev)
+    _, _, xc, xs, rx, _ = cluster.clusterize_device(None, x, voxel)
+    _, _, yc, ys, ry, _ = cluster.clusterize_device(None, y, voxel)
+    rg = cluster.block_ranges_device("within", xc, yc, None, None, rx, ry, (3 * voxel) ** 2)
+    tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    return xs, ys, rg, tup
+
+
+@pytest.mark.parametrize("N,M,D", [(6000, 7000, 3), (3000, 2500, 2), (900, 1100, 1)])
+def test_distance_reductions_on_the_matrix_cores_block_sparse(cuda, N, M, D):
+    """GLHIP_FLAG_MFMA_DIST (glhip_dist_x32.h) on cluster-sorted clouds — what the multiscale backends launch for p = 1 /
+    laplacian: soft-min (plain and fused half-step), laplacian and energy products against the C oracle with the same ranges
+    and against the direct-difference VALU operators."""
+    voxel = 0.12 if D == 3 else 0.05
+    xs, ys, rg, tup = _clustered(7 + D, N, M, D, cuda, voxel)
+    x, y = xs.cpu().numpy(), ys.cpu().numpy()
+    rng = np.random.default_rng(3)
+    h, v = rng.standard_normal(M).astype(np.float32), (rng.random(M) / M).astype(np.float32)
+    v[::5] *= -1
+    for eps in (0.05, 0.01):
+        ref = oracle_c.softmin(eps, x, y, h, 1, ranges=tup)
+        live = np.isfinite(ref)
+        got = hip.softmin_fwd_raw(xs[None], ys[None], _t(h, cuda)[None], eps, 1, rg, hip.FLAG_MFMA_DIST)[0].cpu().numpy()
+        valu = hip.softmin_fwd_raw(xs[None], ys[None], _t(h, cuda)[None], eps, 1, rg, 0)[0].cpu().numpy()
+        assert np.abs(got[live] - ref[live]).max() < 3e-6 * max(1.0, np.abs(ref[live]).max()), eps
+        assert np.abs(got[live] - valu[live]).max() < 3e-6 * max(1.0, np.abs(ref[live]).max())
+        assert np.isposinf(got[~live]).all()
+        # fused half-step: (prev + damping * softmin(eps, C, logw + pot/eps)) / 2
+        pot, prev = rng.standard_normal(M).astype(np.float32) * 0.1, rng.standard_normal(N).astype(np.float32)
+        step = hip.sinkhorn_step_raw(xs[None], ys[None], _t(h, cuda)[None], _t(pot, cuda)[None], _t(prev, cuda)[None], eps, 0.9, 1, rg,
+                                     hip.FLAG_MFMA_DIST)[0].cpu().numpy()
+        ref_s = 0.5 * (prev + 0.9 * oracle_c.softmin(eps, x, y, h + pot / eps, 1, ranges=tup))
+        assert np.abs(step[live] - ref_s[live]).max() < 3e-6 * max(1.0, np.abs(ref_s[live]).max())
+    for kind, code, blur in (("laplacian", hip.LAPLACIAN, 0.07), ("energy", hip.ENERGY, 1.0)):
+        ref = oracle_c.kconv(kind, x, y, v, blur, ranges=tup)
+        bound = oracle_c.kconv(kind, x, y, np.abs(v), blur, ranges=tup)
+        got = hip.kernel_conv_fwd_raw(code, xs[None], ys[None], _t(v, cuda)[None], blur, rg, hip.FLAG_MFMA_DIST)[0].cpu().numpy()
+        assert np.abs(got - ref).max() < 5e-6 * np.abs(bound).max(), kind
+    # bf16 clouds go through the same kernel
+    gb = hip.softmin_fwd_raw(xs[None].bfloat16(), ys[None].bfloat16(), _t(h, cuda)[None], 0.05, 1, rg, hip.FLAG_MFMA_DIST)[0]
+    vb = hip.softmin_fwd_raw(xs[None].bfloat16(), ys[None].bfloat16(), _t(h, cuda)[None], 0.05, 1, rg, 0)[0]
+    fin = torch.isfinite(vb)
+    assert (gb[fin] - vb[fin]).abs().max().item() < 3e-6 * max(1.0, vb[fin].abs().max().item())
+
+
+def test_distance_reductions_dense_large_launches_sort_their_rows(cuda):
+    """Dense p = 1 soft-min / laplacian / energy launches of >= 5e8 pairs and >= 65536 rows: the Python layer voxel-sorts the rows,
+    runs the matrix-core kernel on a "every row block x all columns" pattern and un-sorts the result.  Against the float64 oracle."""
+    from oracle import oracle_torch64 as o64
+    N, M = 70_000, 8_000
+    g = torch.Generator().manual_seed(2)
+    x, y = torch.rand(N, 3, generator=g).to(cuda), torch.rand(M, 3, generator=g).to(cuda)
+    h = (torch.randn(M, generator=g) * 2).to(cuda)
+    v = (torch.rand(M, generator=g) / M).to(cuda)
+    for eps in (0.05, 0.005):
+        ref = o64.softmin(eps, x, y, h, p=1, device=cuda)
+        out = hip.softmin(eps, x, y, h, p=1)
+        hip.set_distance_on_mfma(False)
+        try:
+            plain = hip.softmin(eps, x, y, h, p=1)
+        finally:
+            hip.set_distance_on_mfma(True)
+        e_new, e_old = np.abs(out.cpu().numpy() - ref).max(), np.abs(plain.cpu().numpy() - ref).max()
+        print(f"p=1 soft-min eps={eps}: max abs error matrix cores {e_new:.2e}, direct differences {e_old:.2e} (|f| <= {np.abs(ref).max():.2f})")
+        assert e_new < 3e-6 * max(1.0, np.abs(ref).max())
+        # one fused half-step of the loop takes the same route (plan cached on the row tensor)
+        pot, prev = torch.randn(M, generator=g).to(cuda) * 0.1, torch.randn(N, generator=g).to(cuda)
+        st = hip.sinkhorn_step(eps, x, y, h, pot, prev, 0.8, p=1)
+        ref_s = 0.5 * (prev.double().cpu().numpy() + 0.8 * o64.softmin(eps, x, y, h + pot / eps, p=1, device=cuda))
+        assert np.abs(st.cpu().numpy() - ref_s).max() < 3e-6 * max(1.0, np.abs(ref_s).max())
+    for kind, blur in (("laplacian", 0.05), ("energy", 1.0)):
+        ref = o64.kconv(kind, x, y, v, blur, device=cuda)
+        out = hip.kernel_conv(kind, x, y, v, blur).cpu().numpy()
+        print(f"{kind}: rel error {np.abs(out - ref).max() / np.abs(ref).max():.2e}")
+        assert np.abs(out - ref).max() < 5e-6 * np.abs(ref).max()
+    # gradients still flow (VALU gradient kernels on the un-sorted cloud)
+    xg = x.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(hip.softmin(0.05, xg, y, h, p=1).sum(), [xg])
+    ref_g = o64.softmin_grad_x(0.05, x, y, h, np.ones(N), p=1, device=cuda)
+    assert relerr(gx.cpu().numpy(), ref_g) < 2e-5
+
+
 def test_empty_clouds(cuda):
     """N = 0 returns an empty result; M = 0 is the reduction over the empty set (+inf potential, zero kernel sum)."""
     x, y0 = torch.rand(5, 3, device=cuda), torch.rand(0, 3, device=cuda)
