@@ -67,6 +67,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerBlock = NW * 32;
     constexpr int kThreads = NW * 64;
     __shared__ uint4 tile[kDistTile * kDistRec];      // [column group of 32][K block 0..4][column]
+    __shared__ float csum[NW][4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,8 +86,37 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     const uint4 kZero = uint4{0u, 0u, 0u, 0u};
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
+        // centre of the pass = mean of its rows (half the worst-case offset of "the first row"): the error of a near pair's
+        // distance grows with the square of the offsets from the centre
         float centre[D];
-        load_point<D, T>(prm.x, row0, centre);
+        {
+            const int cnt = min(row_end, row0 + kRowsPerBlock) - row0;
+            float part[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) part[d] = 0.f;
+            if (tid < cnt) {
+                float xi[D];
+                load_point<D, T>(prm.x, row0 + tid, xi);
+#pragma unroll
+                for (int d = 0; d < D; ++d) part[d] = xi[d];
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                for (int off = 32; off > 0; off >>= 1) part[d] += __shfl_xor(part[d], off, 64);
+            }
+            __syncthreads();      // previous pass done with csum
+            if (lane == 0) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) csum[wave][d] = part[d];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float tot = 0.f;
+                for (int w = 0; w < NW; ++w) tot += csum[w][d];
+                centre[d] = tot / (float)cnt;
+            }
+        }
 
         const int wave_row0 = row0 + wave * 32;
         const bool wave_active = wave_row0 < row_end;

@@ -356,7 +356,7 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
 # p = 1 soft-min / laplacian / energy: large dense launches are voxel-sorted first, so that every row block of the launch is
 # spatially compact — the condition under which the squared distance may come from the MFMA (glhip_dist_x32.h)
 _dist_on_mfma = os.environ.get("GEOMLOSS_HIP_MFMA_DIST", "1") != "0"
-_DIST_MIN_ROWS, _DIST_MIN_PAIRS, _DIST_ROWS_PER_VOXEL, _DIST_COL_CHUNKS = 65536, 5e8, 512, 8
+_DIST_MIN_ROWS, _DIST_MIN_PAIRS, _DIST_ROWS_PER_VOXEL, _DIST_COL_CHUNKS = 65536, 5e8, 256, 8
 
 
 def set_distance_on_mfma(enabled):
@@ -373,7 +373,7 @@ class _CompactRows:
         N, D = x.shape
         xf = x.float()
         extent = (xf.amax(0) - xf.amin(0)).clamp_min(1e-12)
-        voxel = float((extent.prod() * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / D))        # ~512 rows per occupied voxel
+        voxel = float((extent.prod() * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / D))        # ~256 rows per occupied voxel = one row tile of the kernel
         self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, voxel)
         self.x = xs.unsqueeze(0)
         C = ranges.shape[0]

@@ -539,7 +539,8 @@ def test_distance_reductions_dense_large_launches_sort_their_rows(cuda):
             hip.set_distance_on_mfma(True)
         e_new, e_old = np.abs(out.cpu().numpy() - ref).max(), np.abs(plain.cpu().numpy() - ref).max()
         print(f"p=1 soft-min eps={eps}: max abs error matrix cores {e_new:.2e}, direct differences {e_old:.2e} (|f| <= {np.abs(ref).max():.2f})")
-        assert e_new < 3e-6 * max(1.0, np.abs(ref).max())
+        # worst row = the one with the closest neighbour: ~2^-24 (rho + d)^2 / d with rho the voxel diagonal (glhip_dist_x32.h)
+        assert e_new < 2e-6 * max(1.0, np.abs(ref).max())
         # one fused half-step of the loop takes the same route (plan cached on the row tensor)
         pot, prev = torch.randn(M, generator=g).to(cuda) * 0.1, torch.randn(N, generator=g).to(cuda)
         st = hip.sinkhorn_step(eps, x, y, h, pot, prev, 0.8, p=1)
