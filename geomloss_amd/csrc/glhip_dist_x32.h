@@ -17,9 +17,11 @@
 //
 // ACCURACY.  d2 carries the absolute error of the expanded form, ~2^-23 t^2 R^2 with R the distance of the two points from the
 // centre c, so d = sqrt(d2) is off by ~2^-24 t R^2 / d: harmless for far pairs (R ~ d) but not for near pairs seen from a far
-// centre.  This kernel is therefore only used on BLOCK-SPARSE launches whose row blocks are spatially compact (the voxel clusters
-// of the multiscale backends, or the voxel sort the Python drivers apply to large dense launches): c is the first row of the
-// workgroup's row chunk, near pairs then have R <~ cluster diameter, and the error of a potential stays ~2^-24 (rho + d)^2 / d.
+// centre.  Two measures keep that in check: (1) the kernel is only used on BLOCK-SPARSE launches whose row blocks are spatially
+// compact (the voxel clusters of the multiscale backends, or the voxel sort the Python drivers apply to large dense launches),
+// with c = the mean of the rows of the workgroup's pass, so that near pairs have R <~ half a cluster diameter; (2) pairs closer
+// than R / 16 (d2 < 2^-8 |xs_i|^2: ~0.4 % of the blocks) are re-evaluated on explicit differences (exact_near_pairs).  What is
+// left is an error <= ~2^-18 R on the distance of a pair, i.e. < 1e-6 on a potential for clusters of diameter 0.2.
 // The caller opts in with GLHIP_FLAG_MFMA_DIST; everything else stays on the direct-difference operators.
 #pragma once
 
@@ -42,10 +44,43 @@ struct DistParams {
     float clamp2;        // 1e-8 t^2
     float out_scale;     // soft-min: -eps ln 2
     float pot_scale, alpha, beta;
+    float guard;         // pairs with d2 < guard * |xs_i|^2 are re-evaluated on explicit differences (2^-8 by default)
 };
 
 constexpr int kDistRec = 5;                 // 16-byte records per column
 constexpr int kDistTile = 512;              // columns per LDS tile: 512 x 5 x 16 B = 40 KiB
+
+// a scaled column coordinate back from its [y1,y2,y1,y3,y1,y2,y3,y2] record (the three pieces sum to the fp32 value exactly)
+__device__ __forceinline__ float unpack_y(const uint4& r) {
+    return (__uint_as_float(r.x << 16) + __uint_as_float(r.x & 0xFFFF0000u)) + __uint_as_float(r.y & 0xFFFF0000u);
+}
+
+// Near pairs.  The MFMA squared distance of a pair much closer than its offset from the centre (d < R / 16) has lost too many
+// bits to the cancellation |xs|^2 + |ys|^2 - 2 xs.ys; such pairs are rare (1024 pi/3 (1/16)^3 (R/L)^3 per block for clouds of
+// size L: ~0.4 % of the blocks at R/L = 0.1) and are recomputed here on explicit differences of the coordinates kept in LDS.
+// Register k of lane l holds column (k/4)*8 + (l/32)*4 + k%4 of the group (32x32 MFMA result layout).
+template <int D>
+__device__ __forceinline__ void exact_near_pairs(f32x16& d2, float thr, const uint4* __restrict__ group, const float (&xs)[3], int half) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (d2[k] < thr) {
+            const int col = (k >> 2) * 8 + half * 4 + (k & 3);
+            float e = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float df = xs[d] - unpack_y(group[d * 32 + col]);
+                e = __builtin_fmaf(df, df, e);
+            }
+            d2[k] = e;
+        }
+    }
+}
+
+__device__ __forceinline__ float min16(const f32x16& v) {
+    const float a = fminf(fminf(v[0], v[1]), v[2]), b = fminf(fminf(v[3], v[4]), v[5]), c = fminf(fminf(v[6], v[7]), v[8]);
+    const float d = fminf(fminf(v[9], v[10]), v[11]), e = fminf(fminf(v[12], v[13]), v[14]);
+    return fminf(fminf(fminf(a, b), fminf(c, d)), fminf(e, v[15]));
+}
 
 // reduction of one 32 x 32 block: d2 (scaled squared distances), sb (per-column scalar, minus the running max for the soft-min)
 template <int MODE>
@@ -121,6 +156,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         const int wave_row0 = row0 + wave * 32;
         const bool wave_active = wave_row0 < row_end;
         uint4 Xlo, Xhi, Xs;
+        float xs3[3] = {0.f, 0.f, 0.f}, thr;
         {
             const int i = min(wave_row0 + l31, row_end - 1);
             float xi[D];
@@ -129,9 +165,11 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float xs = (xi[d] - centre[d]) * prm.t;
+                xs3[d] = xs;
                 n2 = __builtin_fmaf(xs, xs, n2);
                 a[d] = -2.f * xs;
             }
+            thr = prm.guard * n2;
             const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : kZero, p2 = (D > 2) ? pack_a(a[2]) : kZero;
             Xlo = half ? p1 : p0;
             Xhi = half ? pack_negmax(-n2) : p2;            // block 3 carries + |xs|^2
@@ -177,6 +215,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     const uint4* g = &tile[0];
                     f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                     d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                    if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                     const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
                     float um = kMinusHuge;
 #pragma unroll
@@ -193,6 +232,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     const uint4* g = &tile[G * (32 * kDistRec)];
                     f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                     d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                    if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                     const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
                     stmp += block_sum<MODE>(d2, sb, prm.clamp2);
                 }
@@ -203,6 +243,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         const uint4* g = &tile[G * (32 * kDistRec)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                        if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                         const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], plain, zero16);
                         float u[16], um = kMinusHuge;
 #pragma unroll

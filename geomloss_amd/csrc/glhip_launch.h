@@ -295,6 +295,10 @@ void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int 
 // p = 1 soft-min / laplacian / energy with the squared distance on the matrix cores (glhip_dist_x32.h): block-sparse launches whose
 // row blocks are spatially compact, on the caller's word (GLHIP_FLAG_MFMA_DIST).  Row chunks, column splits and the merge as above.
 constexpr int kDistNW = 8;
+inline float dist_guard() {   // GLHIP_DIST_GUARD: test knob (1e30 = every pair on explicit differences, 0 = none)
+    static const float g = getenv("GLHIP_DIST_GUARD") ? (float)atof(getenv("GLHIP_DIST_GUARD")) : 1.0f / 256.0f;
+    return g;
+}
 
 template <int MODE, int D, typename T, class MergeOp>
 void launch_dist(const DistParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int N, int M,
@@ -446,7 +450,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         const int xdl = (flags & GLHIP_FLAG_F32_MFMA) ? FWD_F32 : (flags & GLHIP_FLAG_XDL16) ? FWD_XDL16 : FWD_X32;
         if constexpr (!BWD) {
             if (p == 1 && use_mfma_dist(flags, n_ranges, B, D)) {
-                DistParams<T> dp{prm.x, prm.y, h, step.pot, step.prev, out, s2, 1e-8f * s2 * s2, out_scale, 1.0f / eps, step.alpha, step.beta};
+                DistParams<T> dp{prm.x, prm.y, h, step.pot, step.prev, out, s2, 1e-8f * s2 * s2, out_scale, 1.0f / eps, step.alpha, step.beta, dist_guard()};
                 if (D == 1) launch_dist<DM_SOFTMIN_P1, 1, T, SoftminFwdOp<1, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
                 else if (D == 2) launch_dist<DM_SOFTMIN_P1, 2, T, SoftminFwdOp<2, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
                 else launch_dist<DM_SOFTMIN_P1, 3, T, SoftminFwdOp<3, 1, true, 1, T>>(dp, prm, rg, n_ranges, N, M, sc, st);
@@ -554,7 +558,7 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
             if constexpr (!BWD) {
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
-                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f};
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
                     if (D == 1) launch_dist<DM_LAPLACIAN, 1, T, ConvOp<GLHIP_LAPLACIAN, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
                     else if (D == 2) launch_dist<DM_LAPLACIAN, 2, T, ConvOp<GLHIP_LAPLACIAN, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
                     else launch_dist<DM_LAPLACIAN, 3, T, ConvOp<GLHIP_LAPLACIAN, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
@@ -568,7 +572,7 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.clamp2 = 1e-8f;
             if constexpr (!BWD) {
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
-                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f};
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f, dist_guard()};
                     if (D == 1) launch_dist<DM_ENERGY, 1, T, ConvOp<GLHIP_ENERGY, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
                     else if (D == 2) launch_dist<DM_ENERGY, 2, T, ConvOp<GLHIP_ENERGY, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
                     else launch_dist<DM_ENERGY, 3, T, ConvOp<GLHIP_ENERGY, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
