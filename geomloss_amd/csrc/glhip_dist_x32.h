@@ -88,7 +88,8 @@ __device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, f
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const float dist = fast_sqrt(fmaxf(d2[k], clamp2));
+        // v_med3_f32: the clamp in ONE instruction (fmaxf costs two: the compiler canonicalises the MFMA result first)
+        const float dist = fast_sqrt(__builtin_amdgcn_fmed3f(d2[k], clamp2, 3.0e38f));
         if (MODE == DM_SOFTMIN_P1) acc[k & 3] += fast_exp2(sb[k] - dist);
         else if (MODE == DM_LAPLACIAN) acc[k & 3] = __builtin_fmaf(fast_exp2(-dist), sb[k], acc[k & 3]);
         else acc[k & 3] = __builtin_fmaf(-dist, sb[k], acc[k & 3]);
@@ -219,7 +220,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
                     float um = kMinusHuge;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) um = fmaxf(um, sb[k] - fast_sqrt(fmaxf(d2[k], prm.clamp2)));
+                    for (int k = 0; k < 16; ++k) um = fmaxf(um, sb[k] - fast_sqrt(__builtin_amdgcn_fmed3f(d2[k], prm.clamp2, 3.0e38f)));
                     um = fmaxf(um, __shfl_xor(um, 32, 64));
                     m = um;
                     if (!half) Xs = pack_negmax(m);
@@ -248,7 +249,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         float u[16], um = kMinusHuge;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
-                            u[k] = sb[k] - fast_sqrt(fmaxf(d2[k], prm.clamp2));
+                            u[k] = sb[k] - fast_sqrt(__builtin_amdgcn_fmed3f(d2[k], prm.clamp2, 3.0e38f));
                             um = fmaxf(um, u[k]);
                         }
                         um = fmaxf(um, __shfl_xor(um, 32, 64));

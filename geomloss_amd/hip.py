@@ -372,8 +372,13 @@ class _CompactRows:
         x = xb[0]
         N, D = x.shape
         xf = x.float()
-        extent = (xf.amax(0) - xf.amin(0)).clamp_min(1e-12)
-        voxel = float((extent.prod() * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / D))        # ~256 rows per occupied voxel = one row tile of the kernel
+        ext = [float(e) for e in (xf.amax(0) - xf.amin(0)).tolist()]
+        live = [e for e in ext if e > 1e-6 * max(max(ext), 1e-30)]                     # axes the cloud really extends along
+        vol = 1.0
+        for e in live:
+            vol *= e
+        # ~256 rows per occupied voxel = one row tile of the kernel; never more than 2^20 voxels along an axis
+        voxel = max((vol * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / max(len(live), 1)), max(ext) / (1 << 20), 1e-30)
         self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, voxel)
         self.x = xs.unsqueeze(0)
         C = ranges.shape[0]
