@@ -551,6 +551,15 @@ def test_distance_reductions_dense_large_launches_sort_their_rows(cuda):
         out = hip.kernel_conv(kind, x, y, v, blur).cpu().numpy()
         print(f"{kind}: rel error {np.abs(out - ref).max() / np.abs(ref).max():.2e}")
         assert np.abs(out - ref).max() < 5e-6 * np.abs(ref).max()
+    # degenerate bounding box (a planar cloud in 3-D) and a far-away cloud: the voxel size adapts, the result does not move
+    for xx, yy in ((x * torch.tensor([1.0, 1.0, 0.0], device=cuda), y * torch.tensor([1.0, 1.0, 0.0], device=cuda)), (x + 500.0, y + 500.0)):
+        got = hip.softmin(0.05, xx, yy, h, p=1)
+        hip.set_distance_on_mfma(False)
+        try:
+            want = hip.softmin(0.05, xx, yy, h, p=1)
+        finally:
+            hip.set_distance_on_mfma(True)
+        assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
     # gradients still flow (VALU gradient kernels on the un-sorted cloud)
     xg = x.clone().requires_grad_(True)
     (gx,) = torch.autograd.grad(hip.softmin(0.05, xg, y, h, p=1).sum(), [xg])
