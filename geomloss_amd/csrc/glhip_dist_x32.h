@@ -25,6 +25,8 @@
 // The caller opts in with GLHIP_FLAG_MFMA_DIST; everything else stays on the direct-difference operators.
 #pragma once
 
+#include <type_traits>
+
 #include "glhip_kconv_ops.h"
 #include "glhip_softmin_x32.h"
 
@@ -176,6 +178,20 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
             Xhi = half ? pack_negmax(-n2) : p2;            // block 3 carries + |xs|^2
             Xs = half ? kZero : kOnes;                     // block 4: the scalar itself (soft-min: rewritten with the running max)
         }
+        // a column can only be a "near" partner (d < R_i / 16) of some row of this pass if it lies within 17/16 of the largest row
+        // offset from the centre: tiles without such a column (nearly all of them once the columns are spatially sorted too) skip
+        // the near-pair test altogether
+        float near2;
+        {
+            float r2 = wave_active ? thr : 0.f;
+            for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+            __syncthreads();
+            if (lane == 0) csum[wave][3] = r2;
+            __syncthreads();
+            float tot = 0.f;
+            for (int w = 0; w < NW; ++w) tot = fmaxf(tot, csum[w][3]);
+            near2 = (prm.guard > 0.f) ? tot / prm.guard * 1.13f : -1.f;     // thr = guard |xs|^2  ->  |xs|^2_max (17/16)^2
+        }
         float m = kMinusHuge, ssum = 0.f;                  // soft-min: lazy running max and sum;  products: ssum only
         bool first_group = true;
 
@@ -185,6 +201,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                 const int n = min(kDistTile, je - j0);
                 const int npad = (n + 31) & ~31;
                 __syncthreads();
+                int near = 0;
                 for (int t = tid; t < npad; t += kThreads) {
                     float ys[3] = {0.f, 0.f, 0.f}, n2 = 0.f, sj = (MODE == DM_SOFTMIN_P1) ? kNegBig : 0.f;
                     if (t < n) {
@@ -206,8 +223,9 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(ys[d]) : kZero;
                     base[3 * 32] = pack_h1(n2);
                     base[4 * 32] = pack_h1(sj);
+                    near |= (t < n && n2 < near2) ? 1 : 0;
                 }
-                __syncthreads();
+                const bool tile_near = __syncthreads_or(near) != 0;      // workgroup-uniform
                 if (!wave_active) continue;
 
                 const int nG = npad / 32;
@@ -216,7 +234,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     const uint4* g = &tile[0];
                     f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                     d2 = mfma_x32(g[64 + rec0], Xhi, d2);
-                    if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
+                    if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                     const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
                     float um = kMinusHuge;
 #pragma unroll
@@ -228,15 +246,21 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     first_group = false;
                     G0 = 1;
                 }
-                float stmp = 0.f;
-                for (int G = G0; G < nG; ++G) {
-                    const uint4* g = &tile[G * (32 * kDistRec)];
-                    f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
-                    d2 = mfma_x32(g[64 + rec0], Xhi, d2);
-                    if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
-                    const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
-                    stmp += block_sum<MODE>(d2, sb, prm.clamp2);
-                }
+                auto main_loop = [&](auto guarded) {
+                    float st = 0.f;
+                    for (int G = G0; G < nG; ++G) {
+                        const uint4* g = &tile[G * (32 * kDistRec)];
+                        f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
+                        d2 = mfma_x32(g[64 + rec0], Xhi, d2);
+                        if constexpr (decltype(guarded)::value) {
+                            if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
+                        }
+                        const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
+                        st += block_sum<MODE>(d2, sb, prm.clamp2);
+                    }
+                    return st;
+                };
+                const float stmp = tile_near ? main_loop(std::true_type{}) : main_loop(std::false_type{});
                 if (MODE == DM_SOFTMIN_P1 && __any(!(stmp < kSumThr))) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
                     const uint4 plain = half ? kZero : kOnes;
@@ -244,7 +268,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         const uint4* g = &tile[G * (32 * kDistRec)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
-                        if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
+                        if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                         const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], plain, zero16);
                         float u[16], um = kMinusHuge;
 #pragma unroll

@@ -364,23 +364,32 @@ def set_distance_on_mfma(enabled):
     _dist_on_mfma = bool(enabled)
 
 
-class _CompactRows:
-    """Voxel-sorted copy of a cloud + a block-sparse pattern "every row block x all columns" (in a few column chunks, so that
-    the column splits of the launch have something to split)."""
+def _voxel_for(x, rows_per_voxel):
+    """Voxel edge that puts ~rows_per_voxel points in an occupied voxel, from the bounding box of the (N, D) cloud."""
+    N, D = x.shape
+    xf = x.float()
+    ext = [float(e) for e in (xf.amax(0) - xf.amin(0)).tolist()]
+    live = [e for e in ext if e > 1e-6 * max(max(ext), 1e-30)]                     # axes the cloud really extends along
+    vol = 1.0
+    for e in live:
+        vol *= e
+    # never more than 2^20 voxels along an axis
+    return max((vol * rows_per_voxel / N) ** (1.0 / max(len(live), 1)), max(ext) / (1 << 20), 1e-30)
 
-    def __init__(self, xb, M):
-        x = xb[0]
-        N, D = x.shape
-        xf = x.float()
-        ext = [float(e) for e in (xf.amax(0) - xf.amin(0)).tolist()]
-        live = [e for e in ext if e > 1e-6 * max(max(ext), 1e-30)]                     # axes the cloud really extends along
-        vol = 1.0
-        for e in live:
-            vol *= e
-        # ~256 rows per occupied voxel = one row tile of the kernel; never more than 2^20 voxels along an axis
-        voxel = max((vol * _DIST_ROWS_PER_VOXEL / N) ** (1.0 / max(len(live), 1)), max(ext) / (1 << 20), 1e-30)
-        self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, voxel)
-        self.x = xs.unsqueeze(0)
+
+class _CompactRows:
+    """Voxel-sorted copies of the two clouds of a dense launch + the block-sparse pattern "every row block x all columns" (in a
+    few column chunks, so that the column splits of the launch have something to split).  Rows: one voxel = one row block, the
+    condition for the matrix-core distances.  Columns: sorted too, so that the tiles a workgroup streams are spatially coherent
+    and only the few tiles that overlap its own voxel run the near-pair test."""
+
+    def __init__(self, xb, yb):
+        x, y = xb[0], yb[0]
+        M = y.shape[0]
+        self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, _voxel_for(x, _DIST_ROWS_PER_VOXEL))
+        self.perm_y, ys, _, _, _, _ = grid_cluster_raw(y.contiguous(), None, _voxel_for(y, 2 * _DIST_ROWS_PER_VOXEL))
+        self.perm, self.perm_y = self.perm.long(), self.perm_y.long()
+        self.x, self.y = xs.unsqueeze(0), ys.unsqueeze(0)
         C = ranges.shape[0]
         nchunk = _DIST_COL_CHUNKS
         step = ((M + nchunk - 1) // nchunk + 31) // 32 * 32
@@ -390,19 +399,26 @@ class _CompactRows:
         slices = (torch.arange(1, C + 1, device=x.device, dtype=torch.int32) * nchunk).contiguous()
         self.ranges = BlockRanges(ranges.contiguous(), slices, red, None, None, None)
 
+    def cols(self, t):
+        """A (1, M) per-column vector in the sorted column order."""
+        return None if t is None else t[:, self.perm_y].contiguous()
+
+    def rows(self, t):
+        return None if t is None else t[:, self.perm].contiguous()
+
     def unsort(self, out_sorted):
         """(1, N, ...) in sorted row order -> original order."""
         out = torch.empty_like(out_sorted)
-        out[0, self.perm.long()] = out_sorted[0]
+        out[0, self.perm] = out_sorted[0]
         return out
 
 
-_plan_cache = []     # [(weakref to the row tensor, its version, M, plan)]: the Sinkhorn loop reduces over the same clouds ~40 times
+_plan_cache = []     # [(weakrefs + versions of the two clouds, plan)]: the Sinkhorn loop reduces over the same clouds ~40 times
 
 
 def _compact_rows(xb, yb, ranges, flags, key=None):
-    """A :class:`_CompactRows` plan when a dense distance-type launch is big enough to be worth the sort, else None.
-    ``key``: the caller's tensor the rows come from — plans are remembered per (tensor, version, M) for a few tensors."""
+    """A :class:`_CompactRows` plan when a dense distance-type launch is big enough to be worth the sorts, else None.
+    ``key``: the caller's (rows, columns) tensors — plans are remembered per pair of tensors (and their versions)."""
     import weakref
     B, N, D = xb.shape
     M = yb.shape[1]
@@ -410,12 +426,13 @@ def _compact_rows(xb, yb, ranges, flags, key=None):
             or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
         return None
     if key is not None:
-        for ref, version, m, plan in _plan_cache:
-            if ref() is key and version == key._version and m == M:
+        kx, ky = key
+        for rx, vx, ry, vy, plan in _plan_cache:
+            if rx() is kx and vx == kx._version and ry() is ky and vy == ky._version:
                 return plan
-    plan = _CompactRows(xb, M)
+    plan = _CompactRows(xb, yb)
     if key is not None:
-        _plan_cache.append((weakref.ref(key), key._version, M, plan))
+        _plan_cache.append((weakref.ref(kx), kx._version, weakref.ref(ky), ky._version, plan))
         del _plan_cache[:-4]
     return plan
 
@@ -432,9 +449,9 @@ class _Softmin(torch.autograd.Function):
         xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        plan = _compact_rows(xb, yb, ranges, flags, key=x) if p == 1 else None
-        if plan is not None:       # large dense p = 1 launch: voxel-sorted rows, squared distances on the matrix cores
-            out = plan.unsort(softmin_fwd_raw(plan.x, yb, hb, eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
+        plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if p == 1 else None
+        if plan is not None:       # large dense p = 1 launch: voxel-sorted clouds, squared distances on the matrix cores
+            out = plan.unsort(softmin_fwd_raw(plan.x, plan.y, plan.cols(hb), eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
         else:
             if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
                 flags |= FLAG_MFMA_DIST            # multiscale: the row blocks are voxel clusters already
@@ -606,10 +623,10 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     pt = None if pot is None else _f32(pot).reshape(B, -1)
     pv = None if prev is None else _f32(prev).reshape(B, -1)
     flags = int(flags) | ENV_FLAGS
-    plan = _compact_rows(xb, yb, ranges, flags, key=x) if p == 1 else None
-    if plan is not None:           # large dense p = 1 launch: voxel-sorted rows (plan cached across the iterations of the loop)
-        pvs = None if pv is None else pv[:, plan.perm.long()].contiguous()
-        out = plan.unsort(sinkhorn_step_raw(plan.x, yb, lw, pt, pvs, eps, damping, p, plan.ranges, flags | FLAG_MFMA_DIST))
+    plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if p == 1 else None
+    if plan is not None:           # large dense p = 1 launch: voxel-sorted clouds (plan cached across the iterations of the loop)
+        out = plan.unsort(sinkhorn_step_raw(plan.x, plan.y, plan.cols(lw), plan.cols(pt), plan.rows(pv), eps, damping, p, plan.ranges,
+                                            flags | FLAG_MFMA_DIST))
     else:
         if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
             flags |= FLAG_MFMA_DIST
@@ -629,11 +646,11 @@ class _KernelConv(torch.autograd.Function):
         # accumulator of the gradient kernel is the product itself.  The backward pass is then elementwise.
         fused = (_fuse_kernel_grad and kind == GAUSSIAN and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
                  and not (flags & FLAG_NO_MFMA))
-        plan = _compact_rows(xb, yb, ranges, flags, key=x) if kind in (LAPLACIAN, ENERGY) else None
+        plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if kind in (LAPLACIAN, ENERGY) else None
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
         elif plan is not None:     # large dense laplacian / energy product: voxel-sorted rows, distances from the matrix cores
-            out, unit = plan.unsort(kernel_conv_fwd_raw(kind, plan.x, yb, vb, blur, plan.ranges, flags | FLAG_MFMA_DIST)), None
+            out, unit = plan.unsort(kernel_conv_fwd_raw(kind, plan.x, plan.y, plan.cols(vb), blur, plan.ranges, flags | FLAG_MFMA_DIST)), None
         else:
             fl = flags
             if kind in (LAPLACIAN, ENERGY) and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
