@@ -22,6 +22,29 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h, const floa
     return rc ? rc : check_launch("glhip_softmin_bwd_x");
 }
 
+int glhip_softmin_fwd_grad(const void* x, const void* y, const float* h, const float* guess, float margin, float* out,
+                           float* grad_unit, int B, int N, int M, int D, float eps, int p, int in_dtype, const int32_t* ranges_i,
+                           const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
+                           size_t workspace_bytes, int flags, void* stream) {
+    int rc = check_common("glhip_softmin_fwd_grad", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
+    if (rc) return rc;
+    if (p != 2 || D > 3 || (flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT)))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd_grad: only p = 2, D <= 3 on the matrix-core kernels (got p %d, D %d, flags %d): "
+                                        "call glhip_softmin_fwd + glhip_softmin_bwd_x", p, D, flags);
+    if (B == 0 || N == 0) return GLHIP_OK;
+    if (!guess || !out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_softmin_fwd_grad: NULL guess / out / grad_unit");
+    if (!(eps > 0.f) || !(margin >= 0.f)) return fail(GLHIP_EINVAL, "glhip_softmin_fwd_grad: eps must be > 0 and margin >= 0");
+    const Ranges rg{ranges_i, slices_i, redranges_j};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
+    StepArgs step;
+    step.shift2 = margin * kLog2e / eps;      // the guess may be this far (in units of LSE2) below the exact value's upper bound
+    rc = (in_dtype == GLHIP_F32)
+             ? softmin_typed<true, float>(x, y, h, out, guess, nullptr, grad_unit, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step)
+             : softmin_typed<true, bf16_t>(x, y, h, out, guess, nullptr, grad_unit, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st, step);
+    return rc ? rc : check_launch("glhip_softmin_fwd_grad");
+}
+
 int glhip_cmin_fwd(const void* x, const void* y, const float* g, float* out, int B, int N, int M, int D, int p, int in_dtype,
                    const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* workspace,
                    size_t workspace_bytes, int flags, void* stream) {

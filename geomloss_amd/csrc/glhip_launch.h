@@ -287,8 +287,8 @@ template <int D, typename T>
 void launch_softmin_bwd_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                              const Scratch& sc, bool x32, hipStream_t st) {
     WsumParams<T> w;
-    w.x = prm.x; w.y = prm.y; w.s = prm.h; w.fwd = prm.fwd; w.g = prm.g; w.out = nullptr; w.gx = prm.gx;
-    w.s2 = prm.s2; w.out_scale = prm.out_scale; w.gscale = 1.f; w.tscale = 1.f;
+    w.x = prm.x; w.y = prm.y; w.s = prm.h; w.fwd = prm.fwd; w.g = prm.g; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = prm.s2; w.out_scale = prm.out_scale; w.gscale = 1.f; w.tscale = prm.shift2;
     launch_wsum<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, x32, st);
 }
 
@@ -359,6 +359,7 @@ SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* 
     prm.pot_scale = 1.0f / eps;
     prm.alpha = alpha;
     prm.beta = beta;
+    prm.shift2 = 0.f;
     return prm;
 }
 
@@ -418,6 +419,7 @@ struct StepArgs {   // fused Sinkhorn half-step; all-default = plain soft-min
     const float* pot = nullptr;
     const float* prev = nullptr;
     float alpha = 1.f, beta = 0.f;
+    float shift2 = 0.f;     // value-and-gradient mode of the gradient kernels
 };
 
 template <bool BWD, typename T>
@@ -446,6 +448,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         prm.pot_scale = 1.0f / eps;
         prm.alpha = step.alpha;
         prm.beta = step.beta;
+        prm.shift2 = step.shift2;
         const bool mfma = (flags & GLHIP_FLAG_NO_MFMA) == 0;
         const int xdl = (flags & GLHIP_FLAG_F32_MFMA) ? FWD_F32 : (flags & GLHIP_FLAG_XDL16) ? FWD_XDL16 : FWD_X32;
         if constexpr (!BWD) {

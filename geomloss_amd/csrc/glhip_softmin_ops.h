@@ -41,6 +41,9 @@ struct SoftminParams {
     const float* prev; // (B,N) or NULL
     float pot_scale;   // 1 / eps
     float alpha, beta; // 1, 0 for the plain soft-min
+    // gradient kernels in "value and gradient" mode (glhip_softmin_fwd_grad): `fwd` is only a GUESS of the soft-min, known to lie
+    // within shift2 (base-2 units of LSE2) below the truth's upper bound; the kernel then also writes the exact value to `out`
+    float shift2;      // 0 for the plain gradient
 };
 
 // dual vector entry j as the kernels see it (natural-log units)
@@ -435,8 +438,9 @@ struct SoftminBwdOp {
         }
         float xi[D_];
         load_point<D_, T>(p.x, (long)b * N + i, xi);
-        const float gi = p.g[(long)b * N + i];
+        const float gi = p.g ? p.g[(long)b * N + i] : 1.f;
         const float inv = (sw > 0.f) ? 1.0f / sw : 0.f;
+        if (p.out) p.out[(long)b * N + i] = p.fwd[(long)b * N + i] + p.out_scale * (p.shift2 + fast_log2(sw));   // value-and-gradient mode
 #pragma unroll
         for (int d = 0; d < D_; ++d) {
             float v;

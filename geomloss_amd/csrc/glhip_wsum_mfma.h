@@ -108,7 +108,8 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     n2 = __builtin_fmaf(xt, xt, n2);
                 }
                 const float ri = -0.5f * prm.s2 * n2;
-                if (MODE == WS_SOFTMIN_BWD) Cop[rt][r] = ri - prm.fwd[(long)b * N + ir] / prm.out_scale;   // -(LSE2 - r_i)
+                // -(LSE2 - r_i); in value-and-gradient mode `fwd` is a guess and tscale the margin that makes it an upper bound
+                if (MODE == WS_SOFTMIN_BWD) Cop[rt][r] = ri - (prm.fwd[(long)b * N + ir] / prm.out_scale + prm.tscale);
                 else Cop[rt][r] = ri;
             }
 #pragma unroll
@@ -220,10 +221,12 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                             float* part = sp.workspace + split * sp.split_stride + ((long)b * N + i) * WsumShape<MODE, D>::kPart;
                             if (MODE == WS_SOFTMIN_BWD) {
                                 if (ns == 1) {
-                                    const float gi = prm.g[(long)b * N + i];
+                                    const float gi = prm.g ? prm.g[(long)b * N + i] : 1.f;
                                     const float inv = (a_[D] > 0.f) ? 1.0f / a_[D] : 0.f;
 #pragma unroll
                                     for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] - a_[d] * inv);
+                                    if (prm.out)   // value-and-gradient mode: the mass turns the guess into the exact soft-min
+                                        prm.out[(long)b * N + i] = prm.fwd[(long)b * N + i] + prm.out_scale * (prm.tscale + fast_log2(a_[D]));
                                 } else {
 #pragma unroll
                                     for (int c = 0; c < NA; ++c) part[c] = a_[c];

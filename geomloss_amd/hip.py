@@ -42,6 +42,8 @@ SIGNATURES = {
                               + _RANGES + _TAIL),
     "glhip_kernel_conv_bwd_x": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                          _c_int] + _RANGES + _TAIL),
+    "glhip_softmin_fwd_grad": (_c_int, [_vp, _vp, _vp, _vp, _c_float, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
+                                        _c_int] + _RANGES + _TAIL),
     "glhip_kernel_conv_fwd_grad": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                             _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
@@ -242,6 +244,23 @@ def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
                                      *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
     _check(rc, lib)
     return gx
+
+
+def softmin_fwd_grad_raw(x, y, h, guess, margin, eps, ranges=None, flags=0):
+    """Soft-min and d out_i / d x_i in one reduction, given a guess within ``margin`` of the answer (``glhip_softmin_fwd_grad``;
+    p = 2, D <= 3) -> (B,N), (B,N,D)."""
+    lib = load_library()
+    B, N, D = x.shape
+    M = y.shape[1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    gu = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
+        rc = lib.glhip_softmin_fwd_grad(x.data_ptr(), y.data_ptr(), h.data_ptr(), guess.data_ptr(), float(margin), out.data_ptr(),
+                                        gu.data_ptr(), B, N, M, D, float(eps), 2, _dtype_code(x), *_range_args(ranges, B), *ws_args,
+                                        int(flags), _stream(x))
+    _check(rc, lib)
+    return out, gu
 
 
 def kernel_conv_fwd_raw(kind, x, y, v, blur, ranges=None, flags=0):
@@ -472,6 +491,47 @@ class _Softmin(torch.autograd.Function):
         g = grad_out.reshape(out.shape).float().contiguous()
         gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
         return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None
+
+
+class _SoftminValueGrad(torch.autograd.Function):
+    """The soft-min together with its x-gradient from ONE reduction, for callers that can bound the answer (the last update of
+    the Sinkhorn loop): forward runs ``glhip_softmin_fwd_grad`` and keeps d out_i / d x_i, backward is an elementwise product."""
+
+    @staticmethod
+    def forward(ctx, x, y, h, eps, guess, margin, ranges, flags):
+        xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
+        if yb.dtype != xb.dtype:
+            yb = yb.to(xb.dtype)
+        out, unit = softmin_fwd_grad_raw(xb, yb, hb, _f32(guess).reshape(hb.shape[0], -1), margin, eps, ranges, flags)
+        ctx.unit, ctx.cfg = unit, (x.shape, x.dtype)
+        return out if batched else out.view(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xshape, xdtype = ctx.cfg
+        g = grad_out.reshape(ctx.unit.shape[0], -1).float()
+        return (g.unsqueeze(-1) * ctx.unit).reshape(xshape).to(xdtype), None, None, None, None, None, None, None
+
+
+_VALUE_GRAD_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_VALUE_GRAD_MIN_PAIRS", "5e8"))
+_VALUE_GRAD_MAX_MARGIN = 25.0       # in units of eps: the weights stay >= exp(-50) of the largest one
+
+
+def softmin_value_and_grad(eps, x, y, h, guess, margin, ranges=None, flags=0):
+    """``softmin(eps, x, y, h)`` (differentiable in x) from one reduction instead of a forward and a backward one, or None when that
+    does not apply: x needs no gradient, p = 2 / D <= 3 kernels only, launches too small to pay for the host check of ``margin``
+    (a device scalar: sup |h - h_previous| * eps), or a margin beyond 25 eps (the loop has not converged: use the two passes)."""
+    if not (torch.is_grad_enabled() and x.requires_grad) or x.shape[-1] > 3 or (int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT):
+        return None
+    rows, cols = x.shape[-2], y.shape[-2]
+    B = 1 if x.dim() == 2 else x.shape[0]
+    if float(B) * rows * cols < _VALUE_GRAD_MIN_PAIRS:
+        return None
+    m = float(margin)                       # the one host round trip of this path
+    if not (m >= 0.0) or m > _VALUE_GRAD_MAX_MARGIN * eps:
+        return None
+    guess = torch.nan_to_num(guess.detach().float(), nan=0.0, posinf=0.0, neginf=0.0)     # rows without columns: any finite guess
+    return _SoftminValueGrad.apply(x, y.detach(), h.detach(), float(eps), guess, m * 1.0001 + 1e-12, ranges, int(flags) | ENV_FLAGS)
 
 
 def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0):

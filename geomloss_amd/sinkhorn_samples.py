@@ -131,6 +131,23 @@ class _HipSoftmin:
         out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges)
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
+    def value_and_grad(self, eps, C, log_w, pot_new, pot_old, f_new, f_old, damping):
+        """The last, differentiable update ``damping * softmin(eps, C, log_w + pot_new / eps)`` with its gradient from ONE reduction
+        (``glhip_softmin_fwd_grad``), or None.  The previous iteration of the loop ran the same soft-min on ``pot_old``: that value,
+        ``(2 f_new - f_old) / damping``, is within ``sup |pot_new - pot_old|`` of the one wanted now (1-Lipschitz)."""
+        x, y = C[0], C[1]
+        if self.p != 2 or pot_old is None or f_old is None or not (torch.is_grad_enabled() and x.requires_grad):
+            return None
+        ranges = C[4] if self.multiscale else None
+        flat = (lambda t: t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
+        guess = (2.0 * f_new - f_old) / damping
+        margin = (pot_new - pot_old).abs().max()
+        out = hip.softmin_value_and_grad(eps, x, y, flat(log_w + pot_new / eps), flat(guess), margin, ranges=ranges)
+        if out is None:
+            return None
+        out = damping * out
+        return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
+
     def _iter4_plan(self, C_xy, a_log, b_log, debias, create):
         """The hip.Iter4Plan of the loop being run, (re)built when the inputs change; None when the one-launch-per-iteration
         path does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the GPU

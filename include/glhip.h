@@ -216,6 +216,21 @@ int glhip_softmin_dense_fwd(const float* C, const float* h, float* out,
                             int B, int N, int M, float eps, void* stream);
 
 /*
+ * Soft-min AND its gradient with respect to the row points in ONE pass (p = 2, D <= 3), for callers that know the answer
+ * approximately — the last, differentiable update of the Sinkhorn loop (sinkhorn_divergence.py:612-623), whose previous iterate
+ * bounds it: the soft-min is 1-Lipschitz in its dual vector, so |out - guess| <= margin := sup_j |h_j - h_j(previous)| * eps.
+ *   guess (B,N): soft-min values for the previous dual vector;  margin >= 0 (natural units, like out).
+ *   out[b,i]          = -eps log sum_j exp(h_j - C_ij / eps)                      (exact, whatever the guess)
+ *   grad_unit[b,i,:]  = d out[b,i] / d x[b,i,:] = sum_j P_ij (x_i - y_j)
+ * The weights are formed relative to guess + margin (an upper bound of out), so none exceeds 1 and their sum is >= exp(-2 margin/eps):
+ * keep margin / eps below ~25 (the caller checks; beyond that run glhip_softmin_fwd + glhip_softmin_bwd_x).  One reduction of the
+ * cost of glhip_softmin_bwd_x instead of a forward plus a backward reduction.
+ */
+int glhip_softmin_fwd_grad(const void* x, const void* y, const float* h, const float* guess, float margin, float* out,
+                           float* grad_unit, int B, int N, int M, int D, float eps, int p, int in_dtype,
+                           const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                           void* workspace, size_t workspace_bytes, int flags, void* stream);
+/*
  * Kernel product AND its gradient with respect to the row points in ONE pass (gaussian kernel, D <= 3):
  *   out[b,i]         = sum_j k(x_i, y_j) v_j                      (what glhip_kernel_conv_fwd returns)
  *   grad_unit[b,i,:] = d out[b,i] / d x[b,i,:] = -(1/blur^2) sum_j v_j k(x_i, y_j) (x_i - y_j)

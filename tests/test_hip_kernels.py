@@ -567,6 +567,37 @@ def test_distance_reductions_dense_large_launches_sort_their_rows(cuda):
     assert relerr(gx.cpu().numpy(), ref_g) < 2e-5
 
 
+@pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (1030, 70_001, 3, None), (257, 300, 2, 3), (300, 200, 1, None)])
+def test_softmin_value_and_gradient_in_one_pass(cuda, N, M, D, B):
+    """glhip_softmin_fwd_grad: the exact soft-min and its row gradient from a GUESS of the soft-min and a margin — whatever the guess,
+    as long as the truth lies within the margin.  Dense, many columns (splits + merge), batched, block-sparse, bf16."""
+    x, y, h = _clouds(71 + N, N, M, D, B=B)
+    eps = 0.02
+    rng = np.random.default_rng(9)
+    ref = oracle_np.softmin_points(eps, x.astype(np.float64), y.astype(np.float64), h.astype(np.float64), 2)
+    refg = oracle_np.softmin_points_grad_x(eps, x.astype(np.float64), y.astype(np.float64), h.astype(np.float64), np.ones(x.shape[:-1]), 2)
+    xt, yt, ht = (_t(a, cuda) if B is not None else _t(a, cuda)[None] for a in (x, y, h))
+    for margin in (1e-4, 0.2, 0.45):             # up to 22 eps off
+        guess = ref + rng.uniform(-margin, margin, ref.shape)
+        gt = _t(guess.astype(np.float32), cuda) if B is not None else _t(guess.astype(np.float32), cuda)[None]
+        out, unit = hip.softmin_fwd_grad_raw(xt.contiguous(), yt.contiguous(), ht.contiguous(), gt.contiguous(), margin * 1.01, eps)
+        out, unit = out.cpu().numpy().reshape(ref.shape), unit.cpu().numpy().reshape(refg.shape)
+        assert np.abs(out - ref).max() < 4e-7 * D + 3e-6 * np.abs(ref).max(), margin
+        assert relerr(unit, refg) < 3e-5, margin
+    if B is None and M < 5000:
+        rg, tup, _, keep, ri = _random_ranges(rng, N, M, 5, 6, 0.5, cuda)
+        refs = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
+        live = np.isfinite(refs)
+        guess = np.where(live, refs, 0.0) + rng.uniform(-0.1, 0.1, N)
+        out, unit = hip.softmin_fwd_grad_raw(xt, yt, ht, _t(guess.astype(np.float32), cuda)[None], 0.11, eps, rg)
+        out = out[0].cpu().numpy()
+        assert np.isposinf(out[~live]).all() and np.abs(out[live] - refs[live]).max() < 1.2e-6 + 3e-6 * np.abs(refs[live]).max()
+        refgs = oracle_c.softmin_grad_x(eps, x, y, h, np.ones(N, np.float32), 2, ranges=tup)
+        assert relerr(unit[0].cpu().numpy()[live], refgs[live]) < 3e-5
+        with pytest.raises(NotImplementedError):
+            hip.softmin_fwd_grad_raw(xt, yt, ht, ht[:, :N] if M >= N else ht, 0.1, eps, flags=hip.FLAG_NO_MFMA)
+
+
 def test_empty_clouds(cuda):
     """N = 0 returns an empty result; M = 0 is the reduction over the empty set (+inf potential, zero kernel sum)."""
     x, y0 = torch.rand(5, 3, device=cuda), torch.rand(0, 3, device=cuda)

@@ -231,3 +231,44 @@ def test_bench_sharded_path_on_rccl_single_rank(cuda):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and "nccl" in rec["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("backend,kw", [("online", dict()), ("online", dict(debias=False)), ("online", dict(reach=0.5)),
+                                         ("multiscale", dict(scaling=0.7)), ("multiscale", dict(scaling=0.7, debias=False))])
+def test_one_reduction_final_update_equals_the_two_pass_one(cuda, monkeypatch, backend, kw):
+    """The last, differentiable update of the loop as ONE reduction (value + gradient from the previous iterate as a bound,
+    glhip_softmin_fwd_grad) against the forward + backward pair it replaces on big launches; forced on at a small size here."""
+    from geomloss_amd import sinkhorn_samples as ss
+    g = torch.Generator().manual_seed(31)
+    shapes = [(None, torch.float32)] + ([(3, torch.bfloat16)] if backend == "online" else [])
+    for B, dtype in shapes:
+        shp = (lambda n: (n, 3)) if B is None else (lambda n: (B, n, 3))
+        x = torch.rand(shp(2500), generator=g).to(cuda).to(dtype).requires_grad_(True)
+        y = (torch.rand(shp(2700), generator=g) * 0.7 + 0.2).to(cuda).to(dtype)
+        L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend=backend, **kw)
+        res = {}
+        for one_pass in (True, False):
+            monkeypatch.setattr(hip, "_VALUE_GRAD_MIN_PAIRS", 0.0 if one_pass else 1e30)
+            ss.set_iteration_fusion(False)        # the fused iteration kernel has its own fused last step
+            try:
+                v = L(x, y).sum()
+                (gx,) = torch.autograd.grad(v, [x])
+                res[one_pass] = (v.item(), gx.float())
+            finally:
+                ss.set_iteration_fusion(True)
+        (v1, g1), (v0, g0) = res[True], res[False]
+        assert abs(v1 - v0) <= 3e-6 * abs(v0) + 1e-9, (backend, kw, v1, v0)
+        gtol = 3e-5 if dtype == torch.float32 else 2 ** -7
+        assert (g1 - g0).abs().max().item() <= gtol * g0.abs().max().item() + 1e-9
+    # the one-pass path really ran
+    calls = []
+    orig = hip.softmin_fwd_grad_raw
+    monkeypatch.setattr(hip, "softmin_fwd_grad_raw", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(hip, "_VALUE_GRAD_MIN_PAIRS", 0.0)
+    ss.set_iteration_fusion(False)
+    try:
+        x = torch.rand(900, 3, generator=g).to(cuda).requires_grad_(True)
+        SamplesLoss("sinkhorn", p=2, blur=0.05, backend=backend, **kw)(x, torch.rand(800, 3, generator=g).to(cuda)).backward()
+    finally:
+        ss.set_iteration_fusion(True)
+    assert len(calls) == (2 if kw.get("debias", True) else 1)
