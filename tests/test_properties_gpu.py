@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from geomloss_amd import SamplesLoss
+from geomloss_amd import SamplesLoss, hip
 
 pytestmark = pytest.mark.gpu
 
