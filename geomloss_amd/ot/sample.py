@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import hip
-from .sinkhorn_ot import SampleCost, SinkhornPotentials, annealing_parameters, max_diameter, sinkhorn_cost, sinkhorn_loop
+from .sinkhorn_ot import SampleCost, annealing_parameters, max_diameter, sinkhorn_cost, sinkhorn_loop
 
 
 class ArrayProperties(NamedTuple):
