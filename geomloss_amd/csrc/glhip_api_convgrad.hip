@@ -28,9 +28,11 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
                                size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_kernel_conv_fwd_grad", x, y, v, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
-    if (kind != GLHIP_GAUSSIAN || D > 3 || (flags & GLHIP_FLAG_NO_MFMA))
-        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: only the gaussian kernel, D <= 3, on the matrix-core kernels "
-                                        "(got kind %d, D %d, flags %d): call glhip_kernel_conv_fwd + glhip_kernel_conv_bwd_x", kind, D, flags);
+    if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY)
+        return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: unknown kernel id %d", kind);
+    if (D > 3)
+        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: D <= 3 only (got D %d): call glhip_kernel_conv_fwd + "
+                                        "glhip_kernel_conv_bwd_x", D);
     if (B == 0 || N == 0) return GLHIP_OK;
     if (!out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: NULL out / grad_unit");
     if (!(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
@@ -41,12 +43,25 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
         using T = decltype(tag);
         ConvParams<T> prm;
         prm.x = static_cast<const T*>(x); prm.y = static_cast<const T*>(y); prm.v = v; prm.out = out; prm.g = nullptr; prm.gx = grad_unit;
-        prm.t = std::sqrt(0.5f * kLog2e) / blur;
-        prm.gscale = -1.0f / (prm.t * blur * blur);
-        prm.clamp2 = 0.f;
-        if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-        else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-        else launch_gauss_fwdgrad<3, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        if (kind == GLHIP_GAUSSIAN) {
+            prm.t = std::sqrt(0.5f * kLog2e) / blur;
+            prm.gscale = -1.0f / (prm.t * blur * blur);
+            prm.clamp2 = 0.f;
+            if (flags & GLHIP_FLAG_NO_MFMA) launch_conv_d<GLHIP_GAUSSIAN, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+            else if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+            else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+            else launch_gauss_fwdgrad<3, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+        } else if (kind == GLHIP_LAPLACIAN) {   // same scales as conv_typed (glhip_launch.h)
+            prm.t = kLog2e / blur;
+            prm.gscale = -1.0f / blur;
+            prm.clamp2 = 1e-8f * kLog2e * kLog2e;
+            launch_conv_d<GLHIP_LAPLACIAN, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+        } else {
+            prm.t = 1.0f;
+            prm.gscale = -1.0f;
+            prm.clamp2 = 1e-8f;
+            launch_conv_d<GLHIP_ENERGY, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+        }
     };
     if (in_dtype == GLHIP_F32) run(float{}); else run(bf16_t{});
     return check_launch("glhip_kernel_conv_fwd_grad");

@@ -30,21 +30,34 @@ struct ConvParams {
     float clamp2;      // laplacian / energy: floor on the scaled squared distance, 1e-8 * t^2 (utils.py:61)
 };
 
-template <int KIND>
+// FAMILY: |.| as m * rsq(m), the arithmetic of the product-and-gradient mode below (which needs rsq for the direction and
+// cannot afford a second transcendental) instead of sqrt(m): about twice the rounding noise of sqrt, but the SAME rounding
+// as that mode, which is what the three terms of one kernel norm need (kernel_samples._kernel_operators).
+template <int KIND, bool FAMILY = false>
 __device__ __forceinline__ float radial_kernel(float d2, float clamp2) {
     if (KIND == GLHIP_GAUSSIAN) return fast_exp2(-d2);
-    if (KIND == GLHIP_LAPLACIAN) return fast_exp2(-fast_sqrt(fmaxf(d2, clamp2)));
-    return -fast_sqrt(fmaxf(d2, clamp2));
+    const float m = fmaxf(d2, clamp2);
+    const float dist = FAMILY ? m * fast_rsq(m) : fast_sqrt(m);
+    if (KIND == GLHIP_LAPLACIAN) return fast_exp2(-dist);
+    return -dist;
 }
 
-template <int KIND, int D_, int R, typename T, bool BWD>
+// MODE 0: product.  MODE 1: gradient, scaled by the incoming g_i.  MODE 2: product AND unit gradient
+// in one pass (acc = { direction sum, product }; gx = gscale * direction sum, no g) — the caller
+// scales the saved unit gradient in backward, so the gradient reduction never runs.  MODE 3: product,
+// rounded exactly like the product of MODE 2 (GLHIP_FLAG_GRAD_FAMILY).
+template <int KIND, int D_, int R, typename T, int MODE>
 struct ConvOp {
     static constexpr int kDim = D_;
     static constexpr int kRows = R;
+    static constexpr bool BWD = MODE == 1 || MODE == 2;
+    static constexpr bool BOTH = MODE == 2;
+    static constexpr bool FAMILY = MODE == 3;
+    static constexpr int kAcc = BOTH ? D_ + 1 : (BWD ? D_ : 1);
     using Params = ConvParams<T>;
     struct RowState {
         float a[R][D_];
-        float acc[R][BWD ? D_ : 1];
+        float acc[R][kAcc];
         float clamp2;
     };
 
@@ -63,7 +76,7 @@ struct ConvOp {
 #pragma unroll
             for (int d = 0; d < D_; ++d) st.a[r][d] = (xi[d] - c[d]) * p.t;
 #pragma unroll
-            for (int d = 0; d < (BWD ? D_ : 1); ++d) st.acc[r][d] = 0.f;
+            for (int d = 0; d < kAcc; ++d) st.acc[r][d] = 0.f;
         }
     }
 
@@ -104,15 +117,32 @@ struct ConvOp {
                 }
                 const float vj = rec_tail<D_>(rc[c]);
                 if (!BWD) {
-                    st.acc[r][0] = __builtin_fmaf(radial_kernel<KIND>(d2, st.clamp2), vj, st.acc[r][0]);
+                    st.acc[r][0] = __builtin_fmaf(radial_kernel<KIND, FAMILY>(d2, st.clamp2), vj, st.acc[r][0]);
                 } else {
                     // weight of the direction (xs - ys):  gaussian k ; laplacian k/|.| ; energy 1/|.|
                     float w;
                     if (KIND == GLHIP_GAUSSIAN) {
-                        w = vj * fast_exp2(-d2);
-                    } else {
+                        const float k = fast_exp2(-d2);
+                        if (BOTH) st.acc[r][D_] = __builtin_fmaf(k, vj, st.acc[r][D_]);   // the product mode's fma
+                        w = vj * k;
+                    } else if (!BOTH) {
                         const float rs = (d2 > st.clamp2) ? fast_rsq(d2) : 0.f;
                         w = (KIND == GLHIP_LAPLACIAN) ? vj * rs * fast_exp2(-d2 * rs) : vj * rs;
+                    } else {
+                        // the product needs the clamped distance itself (utils.py:61), the direction
+                        // still vanishes inside the clamp
+                        const bool far = d2 > st.clamp2;
+                        const float m = fmaxf(d2, st.clamp2);
+                        const float rs = fast_rsq(m);
+                        const float dist = m * rs;            // radial_kernel<KIND, true>, bit for bit
+                        if (KIND == GLHIP_LAPLACIAN) {
+                            const float k = fast_exp2(-dist);
+                            st.acc[r][D_] = __builtin_fmaf(k, vj, st.acc[r][D_]);
+                            w = far ? vj * k * rs : 0.f;
+                        } else {
+                            st.acc[r][D_] = __builtin_fmaf(-dist, vj, st.acc[r][D_]);
+                            w = far ? vj * rs : 0.f;
+                        }
                     }
 #pragma unroll
                     for (int d = 0; d < D_; ++d) st.acc[r][d] = __builtin_fmaf(w, df[d], st.acc[r][d]);
@@ -130,7 +160,8 @@ struct ConvOp {
                 if (!BWD) {
                     p.out[(long)b * N + i] = st.acc[r][0];
                 } else {
-                    const float gi = p.g[(long)b * N + i] * p.gscale;
+                    if (BOTH) p.out[(long)b * N + i] = st.acc[r][D_];
+                    const float gi = BOTH ? p.gscale : p.g[(long)b * N + i] * p.gscale;
 #pragma unroll
                     for (int d = 0; d < D_; ++d) p.gx[((long)b * N + i) * D_ + d] = gi * st.acc[r][d];
                 }
@@ -139,7 +170,7 @@ struct ConvOp {
     }
 
     // column splits: plain partial sums
-    static constexpr int kPartial = BWD ? D_ : 1;
+    static constexpr int kPartial = kAcc;
     static __device__ __forceinline__ void store_partial(const RowState& st, int r, float* dst) {
 #pragma unroll
         for (int d = 0; d < kPartial; ++d) dst[d] = st.acc[r][d];
@@ -156,7 +187,8 @@ struct ConvOp {
         if (!BWD) {
             p.out[(long)b * N + i] = acc[0];
         } else {
-            const float gi = p.g[(long)b * N + i] * p.gscale;
+            if (BOTH) p.out[(long)b * N + i] = acc[D_];
+            const float gi = BOTH ? p.gscale : p.g[(long)b * N + i] * p.gscale;
 #pragma unroll
             for (int d = 0; d < D_; ++d) p.gx[((long)b * N + i) * D_ + d] = gi * acc[d];
         }

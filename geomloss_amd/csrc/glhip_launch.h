@@ -494,7 +494,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
 
 // ---- kernel products ---------------------------------------------------------------------------------
 
-template <int KIND, int D, bool BWD, typename T>
+template <int KIND, int D, int BWD, typename T>   // BWD: ConvOp's MODE (0 product, 1 gradient, 2 both)
 void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
                    hipStream_t st) {
     if (use_two_rows(B, N, n_ranges, sc))
@@ -503,7 +503,7 @@ void launch_conv_r(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int
         launch_mapreduce<ConvOp<KIND, D, 1, T, BWD>>(prm, rg, n_ranges, B, N, M, sc.ws, sc.bytes, sc.allow_split, st, sc.cb);
 }
 
-template <int KIND, bool BWD, typename T>
+template <int KIND, int BWD, typename T>
 void launch_conv_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, int D,
                    const Scratch& sc, hipStream_t st) {
     if (D == 1) launch_conv_r<KIND, 1, BWD, T>(prm, rg, n_ranges, B, N, M, sc, st);
@@ -560,6 +560,10 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.gscale = -1.0f / blur;
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
             if constexpr (!BWD) {
+                if (flags & GLHIP_FLAG_GRAD_FAMILY) {   // rounded like the product-and-gradient kernel (glhip_kconv_ops.h, MODE 3)
+                    launch_conv_d<GLHIP_LAPLACIAN, 3, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+                    return GLHIP_OK;
+                }
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
                     DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
                     if (D == 1) launch_dist<DM_LAPLACIAN, 1, T, ConvOp<GLHIP_LAPLACIAN, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
@@ -574,6 +578,10 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.gscale = -1.0f;
             prm.clamp2 = 1e-8f;
             if constexpr (!BWD) {
+                if (flags & GLHIP_FLAG_GRAD_FAMILY) {   // rounded like the product-and-gradient kernel (glhip_kconv_ops.h, MODE 3)
+                    launch_conv_d<GLHIP_ENERGY, 3, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+                    return GLHIP_OK;
+                }
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
                     DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f, dist_guard()};
                     if (D == 1) launch_dist<DM_ENERGY, 1, T, ConvOp<GLHIP_ENERGY, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);

@@ -21,6 +21,7 @@ GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
 FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST = 1, 2, 4, 8, 16, 32, 64
+FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
 
 # every symbol include/glhip.h declares, with its ctypes signature
 _c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -702,18 +703,18 @@ class _KernelConv(torch.autograd.Function):
         xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        # When x requires gradients, the gaussian product and its row gradient come out of ONE reduction: the mass
-        # accumulator of the gradient kernel is the product itself.  The backward pass is then elementwise.
-        fused = (_fuse_kernel_grad and kind == GAUSSIAN and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
-                 and not (flags & FLAG_NO_MFMA))
-        plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if kind in (LAPLACIAN, ENERGY) else None
+        # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
+        # carries one more accumulator, the product itself.  The backward pass is then elementwise.
+        fused = _fuse_kernel_grad and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
+        plan = None if fused or kind == GAUSSIAN or (flags & FLAG_GRAD_FAMILY) else _compact_rows(xb, yb, ranges, flags, key=(x, y))
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
         elif plan is not None:     # large dense laplacian / energy product: voxel-sorted rows, distances from the matrix cores
             out, unit = plan.unsort(kernel_conv_fwd_raw(kind, plan.x, plan.y, plan.cols(vb), blur, plan.ranges, flags | FLAG_MFMA_DIST)), None
         else:
             fl = flags
-            if kind in (LAPLACIAN, ENERGY) and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+            if (kind in (LAPLACIAN, ENERGY) and ranges is not None and _dist_on_mfma
+                    and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT | FLAG_GRAD_FAMILY))):
                 fl |= FLAG_MFMA_DIST               # multiscale: the row blocks are voxel clusters already
             out, unit = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, fl), None
         ctx.unit = unit

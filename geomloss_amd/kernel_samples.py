@@ -91,12 +91,13 @@ def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
             raise KeyError(name)
         # A kernel norm is a difference of three large terms (two samples of one law: 1e-5 left of 1e-3).  When gradients are on,
         # the products whose first cloud requires them run on the product-and-gradient kernel (hip._KernelConv); the other
-        # products of the same loss are then sent to the kernel of the same family (16x16x32 MFMA tiling, identical exponent
-        # arithmetic) so that the per-term rounding bias stays common to the three terms and cancels as before.
+        # products of the same loss are then sent to the kernel of the same family (gaussian: 16x16x32 MFMA tiling, identical
+        # exponent arithmetic; laplacian / energy: explicit differences with |.| = m rsq(m), bit-identical to the product of
+        # the fused mode) so that the per-term rounding bias stays common to the three terms and cancels.
         flags = 0
-        if (name == "gaussian" and x.shape[-1] <= 3 and torch.is_grad_enabled() and hip.kernel_grad_fusion()
+        if (x.shape[-1] <= 3 and torch.is_grad_enabled() and hip.kernel_grad_fusion()
                 and (x.requires_grad or y.requires_grad)):
-            flags = hip.FLAG_XDL16
+            flags = hip.FLAG_GRAD_FAMILY
         build = lambda u, w, r: _LazyKernel(name, u, w, blur, r, flags)  # noqa: E731
     else:
         dense = kernel_routines[name] if kernel is None else kernel

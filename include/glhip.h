@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 106 /* 0.1.6 */
+#define GLHIP_VERSION 107 /* 0.1.7 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -62,6 +62,9 @@ extern "C" {
 #define GLHIP_FLAG_NO_SPLIT 4 /* never split the columns of a row over several workgroups (ignore the workspace) */
 #define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split */
 #define GLHIP_FLAG_XDL16 16   /* p=2 softmin forward / gaussian product: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 */
+#define GLHIP_FLAG_GRAD_FAMILY GLHIP_FLAG_XDL16 /* kernel products: round like the product of glhip_kernel_conv_fwd_grad of the same
+                                 kind — gaussian: the 16x16x32 tiling above; laplacian / energy: explicit differences with |.| = m rsq(m)
+                                 (bit-identical to that product).  For the other two terms of a kernel norm whose gradient is on. */
 #define GLHIP_FLAG_PREPACK 32 /* pre-pack the columns whatever the launch size (default: launches of >= 5e8 pairs); needs workspace */
 #define GLHIP_FLAG_MFMA_DIST 64 /* p = 1 soft-min forward / laplacian / energy product, block-sparse launches, D <= 3: squared distances on
                                  the matrix cores, centred on each row block (glhip_dist_x32.h).  2-3x fewer VALU instructions; accurate
@@ -237,7 +240,11 @@ int glhip_softmin_fwd_grad(const void* x, const void* y, const float* h, const f
  * i.e. glhip_kernel_conv_bwd_x for grad_out = 1 — the mass accumulator of that reduction IS the product.  The autograd
  * forward of the kernel norms calls this when x requires gradients; the backward pass is then grad_out[b,i] * grad_unit[b,i,:],
  * an elementwise product (kernel_samples.py:92-146 with gradients: 3 + 2 reductions become 3).
- * Other kernels / D > 3 / GLHIP_FLAG_NO_MFMA: GLHIP_EUNSUPPORTED (call the two entry points above).
+ * gaussian: matrix-core kernel (GLHIP_FLAG_NO_MFMA: explicit differences).  laplacian / energy: explicit differences with
+ * |.| = m rsq(m); the product is then bit-identical to glhip_kernel_conv_fwd under GLHIP_FLAG_GRAD_FAMILY, which is what the
+ * three terms of one kernel norm are sent to when gradients are on (their rounding must be common to cancel).  Coincident points (inside the 1e-4
+ * clamp of utils.py:61) add k(0) v_j to the product and nothing to the gradient.  D > 3: GLHIP_EUNSUPPORTED (call the two
+ * entry points above).
  */
 int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const float* v, float* out, float* grad_unit,
                                int B, int N, int M, int D, float blur, int in_dtype,

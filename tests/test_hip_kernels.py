@@ -296,12 +296,15 @@ def test_kernel_conv_grads_vs_oracle(cuda, kind, D):
         assert relerr(gv.cpu().numpy(), oracle_c.kconv(kind, y, x, g, blur)) < tol
 
 
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("N,M,D,B", [(310, 270, 3, None), (1030, 70_001, 3, None), (257, 300, 2, 3), (90, 80, 1, None)])
-def test_gaussian_product_and_gradient_in_one_pass(cuda, N, M, D, B):
+def test_kernel_product_and_gradient_in_one_pass(cuda, kind, N, M, D, B):
     """glhip_kernel_conv_fwd_grad (what the autograd forward runs when x requires gradients) against the two separate
     reductions and the oracle: same product, same gradient, for dense / many-column / batched / bf16 launches."""
     x, y, v = _clouds(53 + N, N, M, D, B=B)
     v = np.abs(v) / M
+    if kind != "gaussian":
+        y[..., :5, :] = x[..., :5, :]          # coincident points: the clamp of utils.py:61 and a zero direction
     blur = 0.12
     g = np.random.default_rng(5).standard_normal(x.shape[:-1]).astype(np.float32)
     res = {}
@@ -309,25 +312,34 @@ def test_gaussian_product_and_gradient_in_one_pass(cuda, N, M, D, B):
         hip.set_kernel_grad_fusion(fused)
         try:
             xt = _t(x, cuda).requires_grad_(True)
-            out = hip.kernel_conv("gaussian", xt, _t(y, cuda), _t(v, cuda), blur)
+            out = hip.kernel_conv(kind, xt, _t(y, cuda), _t(v, cuda), blur)
             (gx,) = torch.autograd.grad(out, [xt], grad_outputs=_t(g, cuda))
             res[fused] = (out.detach().cpu().numpy(), gx.cpu().numpy())
         finally:
             hip.set_kernel_grad_fusion(True)
     assert relerr(res[True][0], res[False][0]) < 2e-5 and relerr(res[True][1], res[False][1]) < 2e-5
+    tol = 1e-4 if kind == "gaussian" else 5e-6
     if B is None:
-        assert relerr(res[True][0], oracle_c.kconv("gaussian", x, y, v, blur)) < 1e-4
-        assert relerr(res[True][1], oracle_c.kconv_grad_x("gaussian", x, y, v, g, blur)) < 1e-4
-    # bf16 clouds and the raw call's refusals
+        assert relerr(res[True][0], oracle_c.kconv(kind, x, y, v, blur)) < tol
+        assert relerr(res[True][1], oracle_c.kconv_grad_x(kind, x, y, v, g, blur)) < tol
+    # the explicit-difference kernels: the product of the fused mode IS the product mode, bit for bit (the three terms of a
+    # kernel norm must share their rounding, kernel_samples._kernel_operators)
+    x3, y3, v3 = (_t(a, cuda).reshape((1,) + a.shape if B is None else a.shape).contiguous() for a in (x, y, v))
+    code = hip.KERNEL_KINDS[kind]
+    fl = hip.FLAG_NO_MFMA | hip.FLAG_GRAD_FAMILY
+    o_fused, _ = hip.kernel_conv_fwd_grad_raw(code, x3, y3, v3, blur, flags=fl)
+    o_plain = hip.kernel_conv_fwd_raw(code, x3, y3, v3, blur, flags=fl)
+    assert torch.equal(o_fused, o_plain)
+    # bf16 clouds
     xb, yb = _t(x, cuda).bfloat16().requires_grad_(True), _t(y, cuda).bfloat16()
-    out = hip.kernel_conv("gaussian", xb, yb, _t(v, cuda), blur)
+    out = hip.kernel_conv(kind, xb, yb, _t(v, cuda), blur)
     (gb,) = torch.autograd.grad(out, [xb], grad_outputs=_t(g, cuda))
-    ref = oracle_c.kconv_grad_x("gaussian", xb.detach().float().cpu().numpy().reshape(-1, D)[:N] if B is None else x, yb.float().cpu().numpy().reshape(-1, D)[:M] if B is None else y, v, g, blur) if B is None else None
-    if ref is not None:
+    if B is None:
+        ref = oracle_c.kconv_grad_x(kind, xb.detach().float().cpu().numpy(), yb.float().cpu().numpy(), v, g, blur)
         assert relerr(gb.float().cpu().numpy(), ref) < 2.0 ** -7
-    x3, y3, v3 = (_t(a, cuda).reshape((1,) + a.shape if B is None else a.shape) for a in (x, y, v))
     with pytest.raises(NotImplementedError):
-        hip.kernel_conv_fwd_grad_raw(hip.LAPLACIAN, x3.contiguous(), y3.contiguous(), v3.contiguous(), blur)
+        hip.kernel_conv_fwd_grad_raw(code, _t(np.zeros((1, 8, 4), np.float32), cuda), _t(np.zeros((1, 8, 4), np.float32), cuda),
+                                     _t(np.zeros((1, 8), np.float32), cuda), blur)
 
 
 @pytest.mark.parametrize("kind", KINDS)
