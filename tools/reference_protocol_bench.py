@@ -43,8 +43,14 @@ CONFIGS = [("gaussian", dict(blur=0.1, truncate=3)), ("energy", dict()),
            ("sinkhorn", dict(p=2, blur=0.05, diameter=1)), ("sinkhorn", dict(p=2, blur=0.01, diameter=1))]
 lines = [f"# {torch.cuda.get_device_name(0)}; seconds per (loss + backward); '-' = not run (tensorized memory / 10 s rule)",
          f"{'config':44s} {'backend':11s} " + " ".join(f"{n:>9d}" for n in NS)]
+FIRST = int(sys.argv[sys.argv.index("--from") + 1]) if "--from" in sys.argv else 0   # resume at this (config, backend) row
+os.makedirs("gpurun_out", exist_ok=True)
+k = -1
 for name, kw in CONFIGS:
     for backend in ("tensorized", "online", "multiscale"):
+        k += 1
+        if k < FIRST:
+            continue
         loss = SamplesLoss(name, backend=backend, **kw)
         row, loops, stop = [], 100, False
         for N in NS:
@@ -59,5 +65,4 @@ for name, kw in CONFIGS:
             if t > MAXTIME: stop = True
         line = f"{name + ' ' + str(kw):44s} {backend:11s} " + " ".join(row)
         print(line, flush=True); lines.append(line)
-os.makedirs("gpurun_out", exist_ok=True)
-open("gpurun_out/reference_protocol.txt", "w").write("\n".join(lines) + "\n")
+        open("gpurun_out/reference_protocol.txt", "w").write("\n".join(lines) + "\n")
