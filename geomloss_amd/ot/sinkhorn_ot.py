@@ -142,7 +142,7 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
         f_ba, g_ab = init(x, y, a, b), init(y, x, b, a)
         f_aa, g_bb = (init(x, x, a, a), init(y, y, b, b)) if debias else (None, None)
 
-        plan = None
+        plan, before = None, None
         fusable = x.shape[1] <= 3 and float(x.shape[0]) * y.shape[0] < 4e9
         if fusable:   # one launch per iteration (glhip_sinkhorn_iter4)
             plan = hip.Iter4Plan(x, y, log_a, log_b, debias)
@@ -151,6 +151,7 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
             eps, rho = eps / 2, None if rho is None else rho / 2
             lam = damping_factor(eps, rho)
             pots = (f_ba, g_ab, f_aa, g_bb) if debias else (f_ba, g_ab)
+            before = pots       # what the last iteration of the loop started from (see `last` below)
             if plan is not None:
                 new = plan.run(eps, lam, tuple(p.view(1, -1) for p in pots))
                 new = tuple(t.view(-1) for t in new)
@@ -166,13 +167,20 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
         torch.set_grad_enabled(prev_grad)
 
     if last_extrapolation:   # :421-432 — coupled, non-averaged update on detached dual vectors
-        def last(which, lw, pot):
+        def last(which, lw, pot, pot_old, f_new, f_old):
             rows, cols = cost.pair(which, grad=True)
-            return lam * hip.softmin(eps, rows, cols, (lw + pot / eps).detach())
+            h = (lw + pot / eps).detach()
+            # The last iteration of the loop ran this soft-min on pot_old: its value (2 f_new - f_old) / lam is within
+            # sup |pot - pot_old| of the one wanted now, which lets big launches produce value and gradient in one reduction
+            # (hip.softmin_value_and_grad; None when that does not apply).
+            out = None if before is None else hip.softmin_value_and_grad(
+                eps, rows, cols, h, (2.0 * f_new - f_old) / lam, (pot - pot_old).abs().max())
+            return lam * (hip.softmin(eps, rows, cols, h) if out is None else out.view(-1))
 
-        f_ba, g_ab = last("xy", log_b, g_ab), last("yx", log_a, f_ba)
+        old = (None,) * 4 if before is None else before
+        f_ba, g_ab = (last("xy", log_b, g_ab, old[1], f_ba, old[0]), last("yx", log_a, f_ba, old[0], g_ab, old[1]))
         if debias:
-            f_aa, g_bb = last("xx", log_a, f_aa), last("yy", log_b, g_bb)
+            f_aa, g_bb = (last("xx", log_a, f_aa, old[2], f_aa, old[2]), last("yy", log_b, g_bb, old[3], g_bb, old[3]))
 
     dbl = lambda t: None if t is None else 2.0 * t   # noqa: E731  (back to the units of C = |x-y|^2)
     return SinkhornPotentials(g_ab=dbl(g_ab), f_ba=dbl(f_ba), f_aa=dbl(f_aa), g_bb=dbl(g_bb))

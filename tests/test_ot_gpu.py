@@ -151,3 +151,31 @@ def test_large_problem_and_gradient(cuda):
     # balanced, no debias: value = <a, f_ba> + <b, g_ab>, and only f_ba's last soft-min sees x as its row cloud
     grad_ref = ref["grad_f_ba"] / N
     assert relerr(gx.cpu().numpy(), grad_ref) < 1e-4
+
+
+def test_last_update_in_one_reduction(cuda, monkeypatch):
+    """The last, differentiable update of `sinkhorn_loop` through hip.softmin_value_and_grad (what launches of >= 5e8 pairs
+    use; forced on at N = 1500 here): same value, potentials and gradient as the forward + backward pair, and the oracle."""
+    from geomloss_amd import hip
+
+    rng = np.random.default_rng(12)
+    N, M = 1500, 1300
+    x, y = rng.random((N, 3)), rng.random((M, 3)) * 0.7 + 0.2
+    for kw in (dict(reg=0.02, max_iter=30), dict(reg=0.05, max_iter=20, unbalanced=0.5)):
+        ref = oracle_ot.solve_sample(x, y, **kw)
+        res = {}
+        for one_pass in (True, False):
+            monkeypatch.setattr(hip, "_VALUE_GRAD_MIN_PAIRS", 0.0 if one_pass else 1e30)
+            calls = []
+            orig = hip.softmin_fwd_grad_raw
+            monkeypatch.setattr(hip, "softmin_fwd_grad_raw", lambda *a, _o=orig, **k: (calls.append(1), _o(*a, **k))[1])
+            xt = torch.from_numpy(x).float().to(cuda).requires_grad_(True)
+            out = ot.solve_sample(xt, torch.from_numpy(y).float().to(cuda), **kw)
+            (gx,) = torch.autograd.grad(out.value, [xt])
+            res[one_pass] = (out.value.item(), out.potential_a.detach().cpu().numpy(), gx.cpu().numpy())
+            monkeypatch.setattr(hip, "softmin_fwd_grad_raw", orig)
+            assert bool(calls) == one_pass
+        assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0])
+        assert relerr(res[True][1], res[False][1]) < 2e-6 and relerr(res[True][2], res[False][2]) < 2e-5
+        assert abs(res[True][0] - ref["value"]) <= 1e-4 * abs(ref["value"])
+        assert relerr(res[True][1], ref["potential_a"]) < 1e-4
