@@ -226,8 +226,10 @@ int glhip_softmin_dense_fwd(const float* C, const float* h, float* out,
  *   out[b,i]          = -eps log sum_j exp(h_j - C_ij / eps)                      (exact, whatever the guess)
  *   grad_unit[b,i,:]  = d out[b,i] / d x[b,i,:] = sum_j P_ij (x_i - y_j)
  * The weights are formed relative to guess + margin (an upper bound of out), so none exceeds 1 and their sum is >= exp(-2 margin/eps):
- * keep margin / eps below ~25 (the caller checks; beyond that run glhip_softmin_fwd + glhip_softmin_bwd_x).  One reduction of the
- * cost of glhip_softmin_bwd_x instead of a forward plus a backward reduction.
+ * keep margin / eps below ~25 (the caller checks; beyond that run glhip_softmin_fwd + glhip_softmin_bwd_x).  Rounding: out is
+ * guess plus a correction of up to 2 margins, so it carries a few ulps of the margin (<= 4e-7 margin, measured by
+ * tools/fuzz_kernels.py) on top of the error of glhip_softmin_fwd.  One reduction of the cost of glhip_softmin_bwd_x instead of a
+ * forward plus a backward reduction.
  */
 int glhip_softmin_fwd_grad(const void* x, const void* y, const float* h, const float* guess, float margin, float* out,
                            float* grad_unit, int B, int N, int M, int D, float eps, int p, int in_dtype,
