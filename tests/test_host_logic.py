@@ -230,6 +230,38 @@ def test_from_matrix_covers_exactly_the_kept_pairs_in_both_orientations():
     assert rg.redranges_j.shape[0] == n_runs
 
 
+def test_kernel_norm_sends_its_three_products_to_one_arithmetic(monkeypatch):
+    """A kernel norm is a difference of three large terms: when gradients are on, the two products that run the one-pass
+    product-and-gradient kernel and the third one must share their rounding (GLHIP_FLAG_GRAD_FAMILY); gradient-free calls
+    keep the default kernels.  Host logic only: the launches are recorded, not run."""
+    from geomloss_amd import kernel_samples as ks
+
+    header = open(os.path.join(ROOT, "include", "glhip.h")).read()
+    assert re.search(r"#define GLHIP_FLAG_GRAD_FAMILY GLHIP_FLAG_XDL16", header) and hip.FLAG_GRAD_FAMILY == hip.FLAG_XDL16
+    seen = []
+
+    def record(kind, x, y, v, blur=0.05, ranges=None, flags=0):
+        seen.append((kind, int(flags), x.requires_grad))
+        return (v.sum(-1, keepdim=True) + 0 * x.sum(-1)).expand(x.shape[:-1]) if v.dim() == x.dim() - 1 else v
+
+    monkeypatch.setattr(hip, "kernel_conv", record)
+    x, y = torch.rand(7, 3), torch.rand(5, 3)
+    a, b = torch.full((7,), 1 / 7), torch.full((5,), 1 / 5)
+    for name in ("gaussian", "laplacian", "energy"):
+        for grad in (False, True):
+            seen.clear()
+            ks.kernel_online(a, x.clone().requires_grad_(grad), b, y, blur=0.1, name=name)
+            assert len(seen) == 3
+            assert {f for _, f, _ in seen} == ({hip.FLAG_GRAD_FAMILY} if grad else {0}), (name, grad, seen)
+        seen.clear()
+        with torch.no_grad():     # inference on leaves that require gradients: default kernels
+            ks.kernel_online(a, x.clone().requires_grad_(True), b, y, blur=0.1, name=name)
+        assert {f for _, f, _ in seen} == {0}
+    seen.clear()                  # D > 3: the generic kernels have no one-pass mode
+    ks.kernel_online(a, torch.rand(7, 5).requires_grad_(True), b, torch.rand(5, 5), blur=0.1, name="gaussian")
+    assert {f for _, f, _ in seen} == {0}
+
+
 # ---- C-ABI ------------------------------------------------------------------------------------------
 
 def test_shared_library_exports_every_declared_symbol():
