@@ -184,6 +184,12 @@ def test_hip_backends_refuse_cpu_tensors_loudly():
         SamplesLoss("gaussian", backend="online")(x, y)
     with pytest.raises(NotImplementedError, match="cost formulas"):
         SamplesLoss("sinkhorn", backend="online", cost="Exp(X-Y)")(x, y)
+    # the refusal is raised inside the hand-disabled autograd region of the loop: it must not leave gradients off
+    assert torch.is_grad_enabled()
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            SamplesLoss("sinkhorn", backend="online")(x, y)
+        assert not torch.is_grad_enabled()
 
 
 # ---- clustering and block-sparse ranges ----------------------------------------------------------
