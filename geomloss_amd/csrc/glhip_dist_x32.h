@@ -8,9 +8,9 @@
 //     d2_ij = |xs_i|^2 + |ys_j|^2 - 2 xs_i . ys_j      xs = t (x - c), ys = t (y - c)
 //       K blocks d < D : y side [y1,y2,y1,y3,y1,y2,y3,y2]       x side pieces of -2 xs_d
 //       K block 3      : y side [N1,N2,N3,1,1,1,0,0] (|ys|^2)    x side [1,1,1,n1,n2,n3,0,0] (|xs|^2)
-// and a third MFMA broadcasts the per-column scalar to the lanes that hold the column's 16 rows:
-//       K block 4      : y side [S1,S2,S3,1,1,1,0,0]             x side [1,1,1,m1,m2,m3,0,0]   (soft-min: S = H_j, m = -running max;
-//                                                                                               kernel products: S = v_j, m = 0)
+// and, for the soft-min, a third MFMA broadcasts the per-column scalar to the lanes that hold the column's 16 rows:
+//       K block 4      : y side [S1,S2,S3,1,1,1,0,0]             x side [1,1,1,m1,m2,m3,0,0]   (S = H_j, m = -running max)
+// (the kernel products read their weight v_j from LDS instead — block_sum_lds — which frees 16 result registers: 8 waves per SIMD)
 // What is left for the VALU per pair: max (the clamp of utils.py:61), v_sqrt_f32, and
 //     soft-min p = 1 : sub, v_exp_f32, add          laplacian : v_exp_f32 (negated input), fma          energy : fma
 // i.e. 5 / 4 / 3 instructions instead of 13 / 10 / 9.
@@ -99,12 +99,35 @@ __device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, f
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// kernel products: the per-column weight read straight from LDS (4 broadcast ds_read_b128 per block) instead of a third MFMA —
+// 16 result registers and one operand less, which is what lets 8 waves per SIMD fit (<= 64 VGPRs; 4 records + 4 bytes per column
+// = 34 KiB of LDS per workgroup).  sg = &weights[first column of the group + 4 * half]: register k <-> column (k/4)*8 + 4*half + k%4.
+template <int MODE>
+__device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __restrict__ sg, float clamp2) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sg + q * 8);
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dist = fast_sqrt(__builtin_amdgcn_fmed3f(d2[q * 4 + r], clamp2, 3.0e38f));
+            if (MODE == DM_LAPLACIAN) acc[r] = __builtin_fmaf(fast_exp2(-dist), sv[r], acc[r]);
+            else acc[r] = __builtin_fmaf(-dist, sv[r], acc[r]);
+        }
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 template <int MODE, int D, typename T, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, MODE == DM_SOFTMIN_P1 ? 1 : 8)     // kernel products: 8 waves per SIMD (<= 64 VGPRs)
 dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerBlock = NW * 32;
     constexpr int kThreads = NW * 64;
-    __shared__ uint4 tile[kDistTile * kDistRec];      // [column group of 32][K block 0..4][column]
+    constexpr bool kWeightsInLds = MODE != DM_SOFTMIN_P1;
+    constexpr int REC = kWeightsInLds ? 4 : kDistRec;
+    __shared__ uint4 tile[kDistTile * REC];           // [column group of 32][K block 0..REC-1][column]
+    __shared__ float weights[kWeightsInLds ? kDistTile : 4];
     __shared__ float csum[NW][4];
 
     const int tid = threadIdx.x;
@@ -218,11 +241,12 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                             sj *= kLog2e;
                         }
                     }
-                    uint4* base = &tile[(t >> 5) * (32 * kDistRec) + (t & 31)];
+                    uint4* base = &tile[(t >> 5) * (32 * REC) + (t & 31)];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) base[d * 32] = (d < D) ? pack_y(ys[d]) : kZero;
                     base[3 * 32] = pack_h1(n2);
-                    base[4 * 32] = pack_h1(sj);
+                    if constexpr (kWeightsInLds) weights[t] = sj;
+                    else base[4 * 32] = pack_h1(sj);
                     near |= (t < n && n2 < near2) ? 1 : 0;
                 }
                 const bool tile_near = __syncthreads_or(near) != 0;      // workgroup-uniform
@@ -249,14 +273,18 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                 auto main_loop = [&](auto guarded) {
                     float st = 0.f;
                     for (int G = G0; G < nG; ++G) {
-                        const uint4* g = &tile[G * (32 * kDistRec)];
+                        const uint4* g = &tile[G * (32 * REC)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
                         if constexpr (decltype(guarded)::value) {
                             if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
                         }
-                        const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
-                        st += block_sum<MODE>(d2, sb, prm.clamp2);
+                        if constexpr (kWeightsInLds) {
+                            st += block_sum_lds<MODE>(d2, &weights[G * 32 + half * 4], prm.clamp2);
+                        } else {
+                            const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
+                            st += block_sum<MODE>(d2, sb, prm.clamp2);
+                        }
                     }
                     return st;
                 };
@@ -265,7 +293,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
                     const uint4 plain = half ? kZero : kOnes;
                     for (int G = G0; G < nG; ++G) {
-                        const uint4* g = &tile[G * (32 * kDistRec)];
+                        const uint4* g = &tile[G * (32 * REC)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
                         if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
