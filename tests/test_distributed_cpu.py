@@ -4,7 +4,6 @@ import os
 import socket
 import sys
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -1,6 +1,5 @@
 """Size-independent properties of the drop-in loss on the GPU (HIP backends)."""
 
-import numpy as np
 import pytest
 import torch
 

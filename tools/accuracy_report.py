@@ -2,7 +2,6 @@
 Writes gpurun_out/accuracy_report.txt.  Uses the oracle only as a checker."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import golden_cases, load_golden, relerr

@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from geomloss_amd import SamplesLoss, hip
+from geomloss_amd import SamplesLoss
 from geomloss_amd.sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from geomloss_amd import sinkhorn_samples as ss
 dev = torch.device("cuda:0")
