@@ -2,7 +2,9 @@
 """bench.py — headline measurement of the hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or — when
+    WORLD_SIZE is not set — bench.py starts its N ranks itself the same way; it exits non-zero rather than fall back to
+    the single-GPU headline when N GPUs are not there or WORLD_SIZE disagrees with --gpus)
 
 Metric (BASELINE.json): soft-min pairs/s at N=M=1e6, D=3, fp32 (+ Sinkhorn wall-clock, + roofline).
 A *pair* is one evaluation of exp(h_j - C(x_i,y_j)/eps) inside one soft-min reduction.
@@ -343,11 +345,14 @@ def run_sharded(args, dev, rank, world):
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+    devs = [None] * world                      # which device every rank really computed on: the curve's n_gpus must be real GPUs
+    dist.all_gather_object(devs, f"{os.uname().nodename}:cuda{dev.index}")
     if rank == 0:
         pairs = cfg4_pairs(B)
         print(json.dumps({
             "metric": "softmin pairs/s of the batch-sharded Sinkhorn loss (BASELINE configs[3]: B=256, N=M=4096 3D bf16)",
-            "value": pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "ranks_seen": dist.get_world_size(),
+            "backend": dist.get_backend(), "devices": sorted(set(devs)), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16 points, f32 dual variables and accumulation", "data": "synthetic",
             "config": {
@@ -360,6 +365,50 @@ def run_sharded(args, dev, rank, world):
             },
             "loss_sum": float(total),
         }), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks here — one process per GPU through
+    `torch.distributed.run`, rendezvous on 127.0.0.1 — and hand rank 0's JSON line through.  Refuses (non-zero exit code,
+    nothing on stdout) instead of falling back to the 1-GPU headline when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+
+    if not (args.single_device or args.dry_run):
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f"[bench] refused: --gpus {args.gpus} but this node exposes {have} GPU(s) "
+                "(use --single-device --backend gloo for a dry run of the sharded path on one GPU)")
+            return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_dry(args, rank, world):
+    """`--dry-run`: the launch / rendezvous / barrier / all-reduce / max-over-ranks plumbing of the N > 1 leg with a stand-in
+    CPU workload and the gloo backend — what a box without GPUs can check.  The line says so and carries no throughput."""
+    import torch.distributed as dist
+
+    from geomloss_amd.distributed import shard_bounds
+    lo, hi = shard_bounds(args.batch, rank, world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = torch.tensor([float(hi - lo)])
+        dist.all_reduce(total)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the batch-sharded leg (no kernels timed)", "value": None, "unit": "pairs/s",
+                          "n_gpus": world, "ranks_seen": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": t.item() / args.steps * 1e3, "dry_run": True, "backend": "gloo",
+                          "items_all_ranks": float(total)}), flush=True)
 
 
 def main():
@@ -375,16 +424,38 @@ def main():
                     help="run the N>1 (batch-sharded) leg even with one rank: exercises process-group init + the RCCL all-reduce on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true",
                     help="dry run of the N>1 path on a 1-GPU box: every rank uses cuda:0 (only with --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N>1 plumbing only (spawn, rendezvous, collectives) on the CPU with gloo: no GPU, no kernels, no throughput")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.single_device and args.backend == "nccl":
+        ap.error("--single-device puts every rank on cuda:0, which RCCL refuses: add --backend gloo")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))      # not under torchrun: start the ranks ourselves
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] refused: launched with WORLD_SIZE={world} but --gpus {args.gpus}; the two must agree")
+        sys.exit(2)
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            run_dry(args, rank, world)
+        finally:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.single_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        log(f"[bench] refused: rank {rank} wants cuda:{local_rank} but the node exposes {torch.cuda.device_count()} GPU(s)")
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -396,6 +467,7 @@ def main():
         return
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
     if args.backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:

@@ -72,3 +72,36 @@ def test_shard_bounds_partition_the_batch():
             assert cuts[0][0] == 0 and cuts[-1][1] == B
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+# ---- bench.py launches its own ranks (`python bench.py --gpus N` outside torchrun) -----------------------------------------
+
+def _run_bench(*args, env=None, timeout=300):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                          env=e, cwd=ROOT)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --dry-run` with WORLD_SIZE unset: bench.py re-launches itself under torch.distributed.run
+    (2 ranks, 127.0.0.1 rendezvous), the ranks meet over gloo, rank 0 prints ONE line with n_gpus = the ranks that really ran."""
+    import json
+    out = _run_bench("--gpus", "2", "--dry-run", "--steps", "3")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["dry_run"] is True and rec["steps"] == 3
+    assert rec["items_all_ranks"] == 256.0          # the two shards of the default batch add up
+
+
+def test_bench_refuses_instead_of_falling_back():
+    """No silent single-GPU headline under `--gpus N`: a WORLD_SIZE that disagrees, or fewer GPUs than ranks, ends with a
+    non-zero exit code and nothing on stdout."""
+    out = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1"})
+    assert out.returncode == 2 and out.stdout.strip() == "" and "refused" in out.stderr
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 64:
+        out = _run_bench("--gpus", "64")
+        assert out.returncode == 3 and out.stdout.strip() == "" and "refused" in out.stderr

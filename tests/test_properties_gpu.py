@@ -213,6 +213,32 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(cuda):
     assert abs(rec["config"]["pairs_per_step"] - 6 * 40 * 4096.0**2) < 1
 
 
+def test_bench_gpus2_without_torchrun(cuda):
+    """`python bench.py --gpus 2 --backend gloo --single-device` with no launcher around it: bench.py starts the two ranks itself
+    (both on cuda:0 here) and reports n_gpus = 2 with the loss of the unsharded batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--backend", "gloo", "--single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
+    assert len(rec["devices"]) == 1                      # --single-device: the line says both ranks shared one GPU
+    sys.path.insert(0, root)
+    import bench
+    x, y = bench.cfg4_batch(cuda, 4, seed=2)
+    ref = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)(x, y).sum().item()
+    assert abs(rec["loss_sum"] - ref) <= 1e-6 * abs(ref)
+
+
 def test_bench_sharded_path_on_rccl_single_rank(cuda):
     """The same leg over the real backend (`nccl` = RCCL): one rank, so that process-group creation, the barrier and the scalar
     all-reduce run through RCCL on this GPU (two ranks cannot share a device under RCCL)."""
