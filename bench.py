@@ -152,12 +152,9 @@ def hot_path_kernels(dev, n=1_000_000):
     add("gaussian_gradient", lambda: hip.kernel_conv_bwd_x_raw(hip.GAUSSIAN, x, y, v, g, blur))
     add("gaussian_product_and_gradient", lambda: hip.kernel_conv_fwd_grad_raw(hip.GAUSSIAN, x, y, v, blur))
     # distance-type reductions: the public entry points (hip.softmin / hip.kernel_conv) voxel-sort the rows of a launch this big and
-    # run the matrix-core distance kernel on them; the sort is inside the timed call (its cache is emptied before every call)
+    # run the matrix-core distance kernel on them; the two sorts are inside the timed call (nothing is cached between calls)
     def fresh(fn):
-        def call():
-            hip._plan_cache.clear()
-            return fn()
-        return call
+        return fn
 
     x2, y2, h1, v1 = x[0], y[0], h[0], v[0]
     add("softmin_fwd_p1", fresh(lambda: hip.softmin(0.05, x2, y2, h1, p=1)), reps=2)

@@ -41,7 +41,14 @@ def cluster_ranges_centroids(x, lab, weights=None, min_weight=1e-9, perm=None):
     (no atomics — the same inputs give the same centroids bit for bit on every run) and exact to ~1e-16 of the total
     mass.  Weights keep their own precision (fp32 for bf16 / fp16 clouds); centroids come back in the dtype of ``x``.
     ``perm``: the stable argsort of ``lab`` when the caller already has it.
+    Like the reference's ``bincount`` version (and like ``glhip_grid_cluster``), nothing here is differentiable: the sums run
+    under ``no_grad`` on detached inputs, so centroids and cluster weights never drag a float64 scan into an autograd graph.
     """
+    with torch.no_grad():
+        return _cluster_ranges_centroids(x.detach(), lab, None if weights is None else weights.detach(), min_weight, perm)
+
+
+def _cluster_ranges_centroids(x, lab, weights, min_weight, perm):
     lab = lab.long().view(-1)
     counts = torch.bincount(lab)          # integer histogram: exact, order-independent
     ends = counts.cumsum(0)
@@ -134,21 +141,10 @@ def clusterize_device(a, x, scale, pre_div=1.0):
 
 
 def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
-    """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``).  ``kind``: "dual_slack"
+    """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``; interval buffers sized from its
+    counting pass once the worst case would be large).  ``kind``: "dual_slack"
     (f_i + g_j > C_ij - thr, sinkhorn_samples.py:512-514) or "within" (|c_i - c_j|^2 <= thr, kernel_samples.py:244-252)."""
     from . import hip
-    if rows.shape[0] * cols.shape[0] > 1 << 25:
-        # the worst-case interval buffers (Cr * Cc / 2 entries, twice) stop being "small" from ~6e3 x 6e3 clusters on: build the
-        # mask like the reference does (dense Cr x Cc, torch) and go through from_matrix
-        with torch.no_grad():
-            r, c = rows.detach().float(), cols.detach().float()
-            d2 = ((r * r).sum(1)[:, None] + (c * c).sum(1)[None, :] - 2 * r @ c.t()).clamp_min(0)
-            if kind == "within":
-                keep = d2 <= thr
-            else:
-                C = d2 / 2 if p == 2 else d2.clamp_min(1e-8).sqrt()
-                keep = f.detach().float().view(-1, 1) + g.detach().float().view(1, -1) > C - thr
-            return from_matrix(ranges_rows, ranges_cols, keep)
     code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
     f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
     return hip.block_ranges_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),

@@ -35,7 +35,7 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
                                         "glhip_kernel_conv_bwd_x", D);
     if (B == 0 || N == 0) return GLHIP_OK;
     if (!out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: NULL out / grad_unit");
-    if (!(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
+    if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);

@@ -6,7 +6,10 @@
 // helpers with torch tensor ops (dozens of small launches, two host round trips each, and 1.2 s of lazily loaded torch code
 // objects on the first call).  Here: a handful of launches on the caller's stream, no host round trip inside the library,
 // deterministic results (fixed-order float64 sums, no atomics on floating-point data).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <climits>
 #include <cstdint>
@@ -145,7 +148,7 @@ size_t sort_temp_bytes(int N) {
     size_t bytes = 0;
     uint64_t* k = nullptr;
     int32_t* v = nullptr;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, v, v, N, 0, 3 * kAxisBits, (hipStream_t)0) != hipSuccess || bytes == 0)
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)N, 0u, (unsigned)(3 * kAxisBits), (hipStream_t)0) != hipSuccess || bytes == 0)
         bytes = (size_t)N * 16 + (1 << 20);   // no device to ask (build box): a bound rocPRIM's merge/onesweep paths stay under
     (void)hipGetLastError();
     return bytes;
@@ -154,7 +157,7 @@ size_t sort_temp_bytes(int N) {
 size_t scan_temp_bytes(int N) {
     size_t bytes = 0;
     int32_t* v = nullptr;
-    if (hipcub::DeviceScan::InclusiveSum(nullptr, bytes, v, v, N, (hipStream_t)0) != hipSuccess || bytes == 0)
+    if (rocprim::inclusive_scan(nullptr, bytes, v, v, (size_t)N, rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess || bytes == 0)
         bytes = (size_t)N * 4 + (1 << 20);
     (void)hipGetLastError();
     return bytes;
@@ -184,11 +187,12 @@ int grid_cluster_typed(const void* x_, const float* w, int N, int D, float pre_d
     (void)hipMemsetAsync(&head->overflow, 0, 2 * sizeof(int), st);
     hipLaunchKernelGGL((bounds_kernel<T>), dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, x, N, D, pre_div, voxel, head);
     hipLaunchKernelGGL((keys_kernel<T>), dim3(blocks), dim3(256), 0, st, x, N, D, pre_div, voxel, head, keys_in, idx_in);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, temp_sort, keys_in, keys_out, idx_in, perm, N, 0, D * kAxisBits, st) != hipSuccess)
+    // rocPRIM's radix sort is stable: equal keys (one voxel) keep the order of their indices, as torch.sort(stable=True) does
+    if (rocprim::radix_sort_pairs(tmp, temp_sort, keys_in, keys_out, idx_in, perm, (size_t)N, 0u, (unsigned)(D * kAxisBits), st) != hipSuccess)
         return fail(GLHIP_ELAUNCH, "glhip_grid_cluster: radix sort failed: %s", hipGetErrorString(hipGetLastError()));
     hipLaunchKernelGGL(flags_kernel, dim3(blocks), dim3(256), 0, st, keys_out, N, flags);
     int32_t* incl = idx_in;   // the unsorted indices are no longer needed
-    if (hipcub::DeviceScan::InclusiveSum(tmp, temp_scan, flags, incl, N, st) != hipSuccess)
+    if (rocprim::inclusive_scan(tmp, temp_scan, flags, incl, (size_t)N, rocprim::plus<int32_t>(), st) != hipSuccess)
         return fail(GLHIP_ELAUNCH, "glhip_grid_cluster: scan failed: %s", hipGetErrorString(hipGetLastError()));
     hipLaunchKernelGGL(ranges_kernel, dim3(blocks), dim3(256), 0, st, incl, N, ranges, n_clusters);
     hipLaunchKernelGGL((centroids_kernel<T>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, x, w, perm, ranges, n_clusters, D, pre_div,
@@ -231,7 +235,7 @@ __device__ __forceinline__ bool keep_pair(const KeepRule& k, int i, int j) {
 template <bool FILL>
 __global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_cols,
                                                    int32_t* __restrict__ counts, const int32_t* __restrict__ slices,
-                                                   int32_t* __restrict__ red, int capacity, int32_t* overflow) {
+                                                   int32_t* __restrict__ red, long long capacity, int32_t* overflow) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Cr) return;
@@ -324,24 +328,56 @@ int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in
                : grid_cluster_typed<bf16_t>(x, weights, N, D, pre_div, voxel, perm, x_sorted, w_sorted, ranges, centroids, weights_c, n_clusters, workspace, workspace_bytes, st);
 }
 
+namespace {
+int check_block_ranges(const char* fn, int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D,
+                       int p, const int32_t* ranges_rows, const int32_t* ranges_cols, const int32_t* slices_rows, const int32_t* slices_cols) {
+    if (kind != GLHIP_KEEP_DUAL_SLACK && kind != GLHIP_KEEP_WITHIN) return fail(GLHIP_EINVAL, "%s: bad kind %d", fn, kind);
+    if (Cr < 0 || Cc < 0 || D < 1) return fail(GLHIP_EINVAL, "%s: bad sizes", fn);
+    if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "%s: p must be 1 or 2", fn);
+    if (Cr == 0 || Cc == 0) return GLHIP_OK;
+    if (!rows || !cols || !ranges_rows || !ranges_cols || !slices_rows || !slices_cols || (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
+        return fail(GLHIP_EINVAL, "%s: NULL pointer", fn);
+    return GLHIP_OK;
+}
+}  // namespace
+
+int glhip_block_ranges_count(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D, int p,
+                             float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, int32_t* slices_rows,
+                             int32_t* slices_cols, int32_t* totals, void* stream) {
+    const int rc = check_block_ranges("glhip_block_ranges_count", kind, rows, cols, f, g, Cr, Cc, D, p, ranges_rows, ranges_cols, slices_rows, slices_cols);
+    if (rc) return rc;
+    if (!totals) return fail(GLHIP_EINVAL, "glhip_block_ranges_count: NULL totals");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (Cr == 0 || Cc == 0) {
+        (void)hipMemsetAsync(totals, 0, 2 * sizeof(int32_t), st);
+        return GLHIP_OK;
+    }
+    const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0LL, nullptr);
+    hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_rows, Cr, slices_rows);
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0LL, nullptr);
+    hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
+    (void)hipMemcpyAsync(totals, slices_rows + (Cr - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(totals + 1, slices_cols + (Cc - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    return check_launch("glhip_block_ranges_count");
+}
+
 int glhip_block_ranges(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D, int p,
                        float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, int32_t* slices_rows, int32_t* red_cols,
-                       int32_t* slices_cols, int32_t* red_rows, int capacity, int32_t* status, void* stream) {
-    if (kind != GLHIP_KEEP_DUAL_SLACK && kind != GLHIP_KEEP_WITHIN) return fail(GLHIP_EINVAL, "glhip_block_ranges: bad kind %d", kind);
-    if (Cr < 0 || Cc < 0 || D < 1 || capacity < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges: bad sizes");
-    if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_block_ranges: p must be 1 or 2");
+                       int32_t* slices_cols, int32_t* red_rows, long long capacity, int32_t* status, void* stream) {
+    const int rc = check_block_ranges("glhip_block_ranges", kind, rows, cols, f, g, Cr, Cc, D, p, ranges_rows, ranges_cols, slices_rows, slices_cols);
+    if (rc) return rc;
+    if (capacity < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges: capacity < 0");
     if (Cr == 0 || Cc == 0) return GLHIP_OK;
-    if (!rows || !cols || !ranges_rows || !ranges_cols || !slices_rows || !red_cols || !slices_cols || !red_rows || !status ||
-        (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
-        return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
+    if (!red_cols || !red_rows || !status) return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
     const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
     // the CSR offsets double as the count buffers of the first pass
-    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0, status);
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0LL, status);
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_rows, Cr, slices_rows);
     hipLaunchKernelGGL((runs_kernel<true>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, nullptr, slices_rows, red_cols, capacity, status);
-    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0, status);
+    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0LL, status);
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
     hipLaunchKernelGGL((runs_kernel<true>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, nullptr, slices_cols, red_rows, capacity, status);
     return check_launch("glhip_block_ranges");

@@ -65,11 +65,16 @@ __device__ __forceinline__ void block_extent(const Ranges& rg, int N, int rows_p
                                              int& row_end, int& q_begin, int& q_end, int bx = blockIdx.x) {
     if (SPARSE) {
         int k = bx;
-        if (rg.chunks) {   // row blocks cut into chunks of at most `rows_per_pass` rows: workgroup bx owns chunk bx
-            if (bx >= rg.chunks[0]) { row_begin = row_end = q_begin = q_end = 0; return; }
+        const int T = rg.chunks ? rg.chunks[0] : 0;
+        if (rg.chunks && T >= 0) {   // row blocks cut into chunks of at most `rows_per_pass` rows: workgroup bx owns chunk bx
+            if (bx >= T) { row_begin = row_end = q_begin = q_end = 0; return; }
             k = rg.chunks[1 + 3 * bx];
             row_begin = rg.chunks[2 + 3 * bx];
             row_end = rg.chunks[3 + 3 * bx];
+        } else if (rg.chunks) {      // the table overflowed (T = -n_ranges): one workgroup per row block, the KeOps granularity
+            if (bx >= -T) { row_begin = row_end = q_begin = q_end = 0; return; }
+            row_begin = rg.ranges_i[2 * k];
+            row_end = rg.ranges_i[2 * k + 1];
         } else {
             row_begin = rg.ranges_i[2 * k];
             row_end = rg.ranges_i[2 * k + 1];
@@ -102,7 +107,8 @@ __device__ __forceinline__ void column_interval(const Ranges& rg, int M, int q, 
 // biggest cluster runs long after the chip has drained.  This single-workgroup kernel cuts every row block into chunks of
 // `rows` rows (the row tile of the kernel that follows) with a block-wide prefix sum over the clusters, so that the grid of
 // the reduction is one workgroup per chunk: chunks[0] = T, chunks[1 + 3c ...] = (row block, first row, end row).  The host
-// only knows the bound T <= n_ranges + N / rows and launches that many workgroups; the surplus exits at once.
+// only knows the bound T <= n_ranges + N / rows (valid for disjoint row blocks) and launches that many workgroups; the surplus
+// exits at once.  chunks[0] < 0 = "table too small, ignore it" (see the end of the kernel).
 static __global__ void __launch_bounds__(1024)
 build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int rows, int32_t* __restrict__ chunks, int capacity) {
     __shared__ int scan[1024];
@@ -136,7 +142,10 @@ build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int 
         if (tid == 1023) carry += scan[1023];
         __syncthreads();
     }
-    if (tid == 0) chunks[0] = min(carry, capacity);
+    // The host sizes the table for DISJOINT row blocks inside [0, N) (n_ranges + N / rows chunks always suffice then).  Overlapping
+    // or out-of-range blocks can need more: instead of dropping the surplus chunks, tell the reduction to ignore the table and run
+    // one workgroup per row block (the grid, >= n_ranges workgroups, covers that too).
+    if (tid == 0) chunks[0] = (carry <= capacity) ? carry : -n_ranges;
 }
 
 template <class Op, bool SPARSE>

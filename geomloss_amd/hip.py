@@ -55,7 +55,8 @@ SIGNATURES = {
     "glhip_cluster_workspace_bytes": (_c_size, [_c_int, _c_int]),
     "glhip_grid_cluster": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, _c_float] + [_vp] * 7 + [_vp, _c_size, _vp]),
     "glhip_block_ranges": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 6
-                           + [_c_int, _vp, _vp]),
+                           + [ctypes.c_longlong, _vp, _vp]),
+    "glhip_block_ranges_count": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 5 + [_vp]),
 }
 KEEP_DUAL_SLACK, KEEP_WITHIN = 0, 1
 
@@ -348,23 +349,35 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True):
     return perm, x_sorted, w_sorted, ranges[:C], cents[:C], w_c[:C]
 
 
+_RANGES_WORST_CASE_MAX = 1 << 20     # intervals: up to here the worst-case buffers (2 x 8 MB) are cheaper than a host round trip
+
+
 def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
-    """Keep rule on cluster pairs -> :class:`BlockRanges` (``glhip_block_ranges``), no host round trip."""
+    """Keep rule on cluster pairs -> :class:`BlockRanges` (``glhip_block_ranges``).
+
+    The interval buffers are sized for the worst case (every other cluster kept: Cr * ceil(Cc / 2)) while that is small —
+    no host round trip — and from the counting pass (``glhip_block_ranges_count``, one read-back of two integers) beyond:
+    the worst case is quadratic in the number of clusters, the real count is not."""
     lib = load_library()
     Cr, D = rows.shape
     Cc = cols.shape[0]
     dev = rows.device
-    cap = max(Cr * ((Cc + 1) // 2), Cc * ((Cr + 1) // 2), 1)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     with torch.cuda.device(dev):
         slices_r = torch.empty(Cr, dtype=torch.int32, device=dev)
         slices_c = torch.empty(Cc, dtype=torch.int32, device=dev)
+        head = (int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, Cc, D, int(p), float(thr),
+                ranges_rows.data_ptr(), ranges_cols.data_ptr())
+        cap = max(Cr * ((Cc + 1) // 2), Cc * ((Cr + 1) // 2), 1)
+        if cap > _RANGES_WORST_CASE_MAX:
+            totals = torch.empty(2, dtype=torch.int32, device=dev)
+            _check(lib.glhip_block_ranges_count(*head, slices_r.data_ptr(), slices_c.data_ptr(), totals.data_ptr(), _stream(rows)), lib)
+            cap = max(max(int(v) for v in totals.tolist()), 1)          # the one host round trip of the big case
         red_c = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         red_r = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-        status = torch.empty(1, dtype=torch.int32, device=dev)
-        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        rc = lib.glhip_block_ranges(int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, Cc, D, int(p), float(thr),
-                                    ranges_rows.data_ptr(), ranges_cols.data_ptr(), slices_r.data_ptr(), red_c.data_ptr(),
-                                    slices_c.data_ptr(), red_r.data_ptr(), cap, status.data_ptr(), _stream(rows))
+        status = torch.empty(1, dtype=torch.int32, device=dev)          # cannot fire: both capacities above always suffice
+        rc = lib.glhip_block_ranges(*head, slices_r.data_ptr(), red_c.data_ptr(), slices_c.data_ptr(), red_r.data_ptr(), cap,
+                                    status.data_ptr(), _stream(rows))
     _check(rc, lib)
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
@@ -433,28 +446,36 @@ class _CompactRows:
         return out
 
 
-_plan_cache = []     # [(weakrefs + versions of the two clouds, plan)]: the Sinkhorn loop reduces over the same clouds ~40 times
+def compact_rows_plan(x, y, ranges=None, flags=0):
+    """A :class:`_CompactRows` plan for the dense distance-type launches (p = 1 soft-min, laplacian / energy products) over the
+    clouds x (N,D)|(1,N,D), y likewise, or None when such launches are too small to be worth the two voxel sorts.
 
-
-def _compact_rows(xb, yb, ranges, flags, key=None):
-    """A :class:`_CompactRows` plan when a dense distance-type launch is big enough to be worth the sorts, else None.
-    ``key``: the caller's (rows, columns) tensors — plans are remembered per pair of tensors (and their versions)."""
-    import weakref
+    A plan holds voxel-sorted COPIES of the two clouds: it is valid as long as their contents do not change, which only the
+    caller knows (``x.data -= ...`` does not even bump ``x._version``).  So nothing is cached here: the loop that owns the clouds
+    builds the plan once and passes it down (``_HipSoftmin`` in sinkhorn_samples.py does, for the ~40 reductions of a Sinkhorn
+    loop); one-off calls of :func:`softmin` / :func:`kernel_conv` build their own — two sorts of ~1 ms against a reduction
+    of ~0.2 s at the sizes where plans apply."""
+    xb = _points(x.detach(), "x")
+    yb = _points(y.detach(), "y")
+    xb, yb = (xb.unsqueeze(0) if xb.dim() == 2 else xb), (yb.unsqueeze(0) if yb.dim() == 2 else yb)
+    if yb.dtype != xb.dtype:
+        yb = yb.to(xb.dtype)
     B, N, D = xb.shape
     M = yb.shape[1]
+    flags = int(flags) | ENV_FLAGS
     if (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS
             or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
         return None
-    if key is not None:
-        kx, ky = key
-        for rx, vx, ry, vy, plan in _plan_cache:
-            if rx() is kx and vx == kx._version and ry() is ky and vy == ky._version:
-                return plan
-    plan = _CompactRows(xb, yb)
-    if key is not None:
-        _plan_cache.append((weakref.ref(kx), kx._version, weakref.ref(ky), ky._version, plan))
-        del _plan_cache[:-4]
-    return plan
+    return _CompactRows(xb, yb)
+
+
+def _plan_for(plan, xb, yb, ranges, flags):
+    """The caller's plan if it fits this launch, else a fresh one (or None)."""
+    if plan is not None:
+        if ranges is not None or plan.x.shape != xb.shape or plan.y.shape != yb.shape or plan.x.dtype != xb.dtype:
+            raise ValueError("geomloss_amd: the compact-rows plan was built for other clouds than the ones of this call.")
+        return plan
+    return compact_rows_plan(xb, yb, ranges, flags)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -465,11 +486,11 @@ class _Softmin(torch.autograd.Function):
     """f_i = -eps log sum_j exp(h_j - C(x_i,y_j)/eps); differentiable in x only, like the reference's call sites."""
 
     @staticmethod
-    def forward(ctx, x, y, h, eps, p, ranges, flags):
+    def forward(ctx, x, y, h, eps, p, ranges, flags, plan=None):
         xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if p == 1 else None
+        plan = _plan_for(plan, xb, yb, ranges, flags) if p == 1 else None
         if plan is not None:       # large dense p = 1 launch: voxel-sorted clouds, squared distances on the matrix cores
             out = plan.unsort(softmin_fwd_raw(plan.x, plan.y, plan.cols(hb), eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
         else:
@@ -491,7 +512,7 @@ class _Softmin(torch.autograd.Function):
         eps, p, ranges, flags, xshape, xdtype = ctx.cfg
         g = grad_out.reshape(out.shape).float().contiguous()
         gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
-        return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None
+        return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None, None
 
 
 class _SoftminValueGrad(torch.autograd.Function):
@@ -667,12 +688,13 @@ def sinkhorn_last4(plan, x, y, eps, damping, pots):
 ENV_FLAGS = int(os.environ.get("GEOMLOSS_HIP_FLAGS", "0"))
 
 
-def softmin(eps, x, y, h, p=2, ranges=None, flags=0):
-    """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32."""
-    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS)
+def softmin(eps, x, y, h, p=2, ranges=None, flags=0, plan=None):
+    """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32.
+    ``plan``: a :func:`compact_rows_plan` of (x, y) that the caller keeps across calls (p = 1, large dense launches)."""
+    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS, plan)
 
 
-def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0):
+def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0, plan=None):
     """One fused, non-differentiable half-step of the Sinkhorn loop on the GPU (D <= 3).
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); logw, pot: (M,)|(B,M) (pot may be None); prev: (N,)|(B,N) or None.
@@ -684,8 +706,8 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     pt = None if pot is None else _f32(pot).reshape(B, -1)
     pv = None if prev is None else _f32(prev).reshape(B, -1)
     flags = int(flags) | ENV_FLAGS
-    plan = _compact_rows(xb, yb, ranges, flags, key=(x, y)) if p == 1 else None
-    if plan is not None:           # large dense p = 1 launch: voxel-sorted clouds (plan cached across the iterations of the loop)
+    plan = _plan_for(plan, xb, yb, ranges, flags) if p == 1 else None
+    if plan is not None:           # large dense p = 1 launch: voxel-sorted clouds (the loop passes its plan: built once per loss)
         out = plan.unsort(sinkhorn_step_raw(plan.x, plan.y, plan.cols(lw), plan.cols(pt), plan.rows(pv), eps, damping, p, plan.ranges,
                                             flags | FLAG_MFMA_DIST))
     else:
@@ -706,7 +728,7 @@ class _KernelConv(torch.autograd.Function):
         # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
         # carries one more accumulator, the product itself.  The backward pass is then elementwise.
         fused = _fuse_kernel_grad and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
-        plan = None if fused or kind == GAUSSIAN or (flags & FLAG_GRAD_FAMILY) else _compact_rows(xb, yb, ranges, flags, key=(x, y))
+        plan = None if fused or kind == GAUSSIAN or (flags & FLAG_GRAD_FAMILY) else compact_rows_plan(xb, yb, ranges, flags)
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
         elif plan is not None:     # large dense laplacian / energy product: voxel-sorted rows, distances from the matrix cores

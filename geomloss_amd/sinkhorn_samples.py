@@ -103,10 +103,10 @@ def _fp32_weights(a, b):
     return a, b
 
 
-def softmin_online(eps, C_xy, h_y, p=2):
+def softmin_online(eps, C_xy, h_y, p=2, plan=None):
     """Soft-C-transform on implicit costs (``:337-346`` and ``:229-290``): C_xy = (x, y), batched or not."""
     x, y = C_xy
-    out = hip.softmin(eps, x, y, h_y, p=p)
+    out = hip.softmin(eps, x, y, h_y, p=p, plan=plan)
     return out if x.dim() > 2 else out.view(1, -1)
 
 
@@ -117,9 +117,24 @@ class _HipSoftmin:
     def __init__(self, p, multiscale):
         self.p, self.multiscale = p, multiscale
         self._plan = None   # (x, y, a_log, b_log, debias, hip.Iter4Plan) of the loop being run
+        self._dist_plans = {}   # p = 1, dense: (id(x), id(y)) -> (x, y, hip.compact_rows_plan): voxel-sorted copies, per loop
+
+    def _dist_plan(self, x, y):
+        """The voxel-sorted copies of (x, y) behind the matrix-core distance kernel, built once for the ~10 reductions the loop
+        runs over this pair of clouds.  This object lives for one loss evaluation and holds the tensors it keys on, so a plan can
+        neither outlive its clouds nor see them change (the loop never writes to them)."""
+        if self.p != 1 or self.multiscale or x.dim() != 2:
+            return None
+        key = (id(x), id(y))
+        hit = self._dist_plans.get(key)
+        if hit is None:
+            hit = self._dist_plans[key] = (x, y, hip.compact_rows_plan(x, y))
+        return hit[2]
 
     def __call__(self, eps, C, h):
-        return softmin_multiscale(eps, C, h, p=self.p) if self.multiscale else softmin_online(eps, C, h, p=self.p)
+        if self.multiscale:
+            return softmin_multiscale(eps, C, h, p=self.p)
+        return softmin_online(eps, C, h, p=self.p, plan=self._dist_plan(C[0], C[1]))
 
     def step(self, eps, C, log_w, pot, damping, prev):
         x, y = C[0], C[1]
@@ -128,7 +143,8 @@ class _HipSoftmin:
             ft = damping * self(eps, C, log_w if pot is None else log_w + pot / eps)
             return ft if prev is None else 0.5 * (prev + ft)
         flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
-        out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges)
+        out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges,
+                                plan=self._dist_plan(x, y))
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
     def value_and_grad(self, eps, C, log_w, pot_new, pot_old, f_new, f_old, damping):

@@ -25,8 +25,11 @@
  * Block-sparse reductions ("ranges", KeOps convention, int32 device arrays;
  * built at sinkhorn_samples.py:515 / kernel_samples.py:254-256 by
  * pykeops.torch.cluster.from_matrix):
- *   ranges_i    (n_ranges, 2)  row blocks [start, end) — rows outside every
- *                              block are left untouched in the output
+ *   ranges_i    (n_ranges, 2)  row blocks [start, end) inside [0, N) — rows outside every
+ *                              block are left untouched in the output.  Blocks are meant to be disjoint
+ *                              (clusters of a sorted cloud); overlapping blocks are reduced correctly (a row
+ *                              in two blocks is written by both) but one workgroup per block, without the
+ *                              load-balancing row chunks
  *   slices_i    (n_ranges,)    CSR end offsets into redranges_j; block k owns
  *                              redranges_j[slices_i[k-1] : slices_i[k]] (slices_i[-1] = 0)
  *   redranges_j (nnz, 2)       column intervals [start, end) to reduce over
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 107 /* 0.1.7 */
+#define GLHIP_VERSION 108 /* 0.1.8 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -70,6 +73,14 @@ extern "C" {
                                  the matrix cores, centred on each row block (glhip_dist_x32.h).  2-3x fewer VALU instructions; accurate
                                  (~2^-24 (rho + d)^2 / d on a potential, rho = row-block diameter) when row blocks are spatially compact:
                                  the caller's responsibility (voxel clusters of the multiscale backends, voxel-sorted dense clouds). */
+
+/* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
+ *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
+ *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
+ *                             on explicit differences (default 2^-8; 1e30 = every pair, used by the tests to check the register
+ *                             <-> column map; 0 = none)
+ * They are latched in function-local statics on first use: the library keeps no other global state (re-entrant apart from the
+ * thread-local error string). */
 
 /* error codes */
 #define GLHIP_OK 0
@@ -291,8 +302,9 @@ int glhip_max_lines_fwd(const float* g, float* out, long R, int N, float step, i
  *   out: slices_rows (Cr) + red_cols (capacity,2) = the (slices_i, redranges_j) of a reduction over the columns of every
  *        row cluster, slices_cols (Cc) + red_rows (capacity,2) = the same for the transposed reduction.  Kept column
  *        clusters that are adjacent in memory are merged into one interval (same pair set, fewer and longer tiles).
- *   capacity: intervals each `red_*` array can hold; Cr * ((Cc + 1) / 2) (resp. Cc * ((Cr + 1) / 2)) always suffices.
- *   status (1) int32 out: != 0 if capacity was exceeded.
+ *   capacity: intervals each `red_*` array can hold (64-bit); Cr * ((Cc + 1) / 2) (resp. Cc * ((Cr + 1) / 2)) always suffices,
+ *             glhip_block_ranges_count gives the exact number.
+ *   status (1) int32 out: != 0 if capacity was exceeded (intervals beyond it are dropped, never written out of bounds).
  */
 #define GLHIP_KEEP_DUAL_SLACK 0
 #define GLHIP_KEEP_WITHIN 1
@@ -302,8 +314,15 @@ int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in
                        float* weights_c, int32_t* n_clusters, void* workspace, size_t workspace_bytes, void* stream);
 int glhip_block_ranges(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
                        int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
-                       int32_t* slices_rows, int32_t* red_cols, int32_t* slices_cols, int32_t* red_rows, int capacity,
+                       int32_t* slices_rows, int32_t* red_cols, int32_t* slices_cols, int32_t* red_rows, long long capacity,
                        int32_t* status, void* stream);
+/* The counting half of glhip_block_ranges alone: writes the CSR offsets slices_rows (Cr) / slices_cols (Cc) and
+ * totals (2) = { number of intervals of the row-major pattern, of the column-major pattern } (= the last offsets).  A caller that
+ * reads `totals` back can size red_cols / red_rows exactly instead of for the worst case (which is quadratic in the number of
+ * clusters: 3.2 GB at 2e4 clusters a side) and then call glhip_block_ranges with capacity = max(totals). */
+int glhip_block_ranges_count(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
+                             int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
+                             int32_t* slices_rows, int32_t* slices_cols, int32_t* totals, void* stream);
 #ifdef __cplusplus
 }
 #endif

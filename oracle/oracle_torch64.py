@@ -127,13 +127,18 @@ def softmin_grad_x(eps, x, y, h, g, p=2, device=None, rows=None, budget=_BUDGET)
 
 def _kernel_rows(kind, xb, y, blur):
     """(R, M) kernel values and, for the gradient, the (R, M) factor c_ij with dk/dx_i = c_ij (x_i - y_j)."""
+    if kind == "gaussian":          # exp(-|x-y|^2 / (2 blur^2)), kernel_samples.py:62-68
+        # one addmm instead of 3 D elementwise passes: -|x-y|^2/2b^2 = x.y/b^2 - |x|^2/2b^2 - |y|^2/2b^2, the reference's own
+        # expansion (utils.py:42-49); the callers centre the clouds, so the cancellation costs ~1e-16 diam^2 / blur^2
+        ib2 = 1.0 / (blur * blur)
+        K = torch.addmm((-0.5 * ib2 * (y * y).sum(1)).unsqueeze(0), xb, y.t(), alpha=ib2)
+        K += (-0.5 * ib2 * (xb * xb).sum(1)).unsqueeze(1)
+        K.clamp_max_(0.0).exp_()
+        return K, -ib2
     d2 = torch.zeros((xb.shape[0], y.shape[0]), dtype=F64, device=xb.device)
     for d in range(xb.shape[1]):
         diff = xb[:, d:d + 1] - y[:, d].unsqueeze(0)
         d2 += diff * diff
-    if kind == "gaussian":          # exp(-|x-y|^2 / (2 blur^2)), kernel_samples.py:62-68
-        K = torch.exp(-d2 / (2 * blur * blur))
-        return K, -K / (blur * blur)
     if kind == "laplacian":         # exp(-sqrt(clamp_min(|x/blur - y/blur|^2, 1e-8))), :71-77
         s2 = d2 / (blur * blur)
         live = s2 > 1e-8
@@ -153,6 +158,7 @@ def kconv(kind, x, y, v, blur=0.05, device=None, rows=None, budget=_BUDGET):
     x, y, v = _t(x, device), _t(y, device), _t(v, device).reshape(-1)
     if rows is not None:
         x = x[torch.as_tensor(rows, device=device)]
+    x, y = _centred(x, y)
     out = torch.empty(x.shape[0], dtype=F64, device=device)
     for i0, i1 in _chunks(x.shape[0], y.shape[0], budget // 2):
         K, _ = _kernel_rows(kind, x[i0:i1], y, blur)
@@ -167,11 +173,12 @@ def kconv_grad_x(kind, x, y, v, g, blur=0.05, device=None, rows=None, budget=_BU
     if rows is not None:
         sel = torch.as_tensor(rows, device=device)
         x, g = x[sel], g[sel]
+    x, y = _centred(x, y)
     out = torch.empty_like(x)
     for i0, i1 in _chunks(x.shape[0], y.shape[0], budget // 2):
         xb = x[i0:i1]
-        _, c = _kernel_rows(kind, xb, y, blur)
-        cv = c * v.unsqueeze(0)
+        K, c = _kernel_rows(kind, xb, y, blur)
+        cv = K.mul_(c).mul_(v.unsqueeze(0)) if kind == "gaussian" else c * v.unsqueeze(0)     # gaussian: c = -K / blur^2
         out[i0:i1] = g[i0:i1, None] * (xb * cv.sum(1, keepdim=True) - cv @ y)   # sum_j c_ij v_j (x_i - y_j)
     return _np(out)
 
@@ -220,22 +227,22 @@ def sinkhorn_loss(x, y, a=None, b=None, p=2, blur=0.05, reach=None, diameter=Non
     return float(out), gx, ga
 
 
-def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, grad=False, device=None):
+def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, grad=False, device=None, budget=_BUDGET):
     """SamplesLoss(name, backend="online")(a, x, b, y) for one pair of clouds; with ``grad``: (loss, dL/dx, dL/da)."""
     device = default_device() if device is None else device
     xn, yn = _host64(x), _host64(y)
     a, b = _weights(xn.shape[0], a), _weights(yn.shape[0], b)
     xt, yt = _t(xn, device), _t(yn, device)
-    a_x = kconv(name, xt, xt, a, blur, device)
-    b_y = kconv(name, yt, yt, b, blur, device)
-    b_x = kconv(name, xt, yt, b, blur, device)
+    a_x = kconv(name, xt, xt, a, blur, device, budget=budget)
+    b_y = kconv(name, yt, yt, b, blur, device, budget=budget)
+    b_x = kconv(name, xt, yt, b, blur, device, budget=budget)
     if potentials:
-        return a_x - b_x, b_y - kconv(name, yt, xt, a, blur, device)
+        return a_x - b_x, b_y - kconv(name, yt, xt, a, blur, device, budget=budget)
     loss = float(0.5 * a @ a_x + 0.5 * b @ b_y - a @ b_x)
     if not grad:
         return loss
     # DoubleGrad (kernel_samples.py:43-54) doubles the half of the symmetric term that autograd sees
-    gx = kconv_grad_x(name, xt, xt, a, a, blur, device) - kconv_grad_x(name, xt, yt, b, a, blur, device)
+    gx = kconv_grad_x(name, xt, xt, a, a, blur, device, budget=budget) - kconv_grad_x(name, xt, yt, b, a, blur, device, budget=budget)
     return loss, gx, a_x - b_x
 
 
@@ -244,60 +251,103 @@ def kernel_loss(name, x, y, a=None, b=None, blur=0.05, potentials=False, grad=Fa
 # --------------------------------------------------------------------------------------------------
 
 
+_FINE_BUDGET = 1 << 27   # matrix entries per fine-level chunk (1 GB in float64)
+
+
+def _plan_groups(keep, nx, ny, budget):
+    """Runs [k0, k1) of consecutive row clusters whose rows x (union of their kept columns) fit the budget.  Clusters that are
+    neighbours in the lexicographic voxel order keep nearly the same column clusters, so a run costs little more than its
+    members one by one (the pairs outside a member's own keep set are masked out again: same pair set as the reference)."""
+    groups, k, C = [], 0, keep.shape[0]
+    while k < C:
+        u, rows, k1 = keep[k].copy(), int(nx[k]), k + 1
+        while k1 < C:
+            u2, rows2 = u | keep[k1], rows + int(nx[k1])
+            if rows2 * int(ny[u2].sum()) > budget:
+                break
+            u, rows, k1 = u2, rows2, k1 + 1
+        groups.append((k, k1))
+        k = k1
+    return groups
+
+
 class _FineCost:
     """Fine-level cost object: cluster-sorted clouds (device, float64) + an optional cluster-level keep mask."""
 
     def __init__(self, x, y, ranges_x, ranges_y, keep=None):
-        self.x, self.y, self.ranges_x, self.ranges_y, self.keep = x, y, ranges_x, ranges_y, keep
+        self.x, self.y, self.ranges_x, self.ranges_y = x, y, np.asarray(ranges_x), np.asarray(ranges_y)
+        self.keep = None
         if keep is not None:
-            ny = torch.as_tensor(ranges_y[:, 1] - ranges_y[:, 0], device=y.device)
-            self.col_label = torch.repeat_interleave(torch.arange(len(ranges_y), device=y.device), ny)
+            dev = x.device
+            nx, ny = self.ranges_x[:, 1] - self.ranges_x[:, 0], self.ranges_y[:, 1] - self.ranges_y[:, 0]
+            self.keep = torch.as_tensor(np.ascontiguousarray(keep), device=dev)
+            self.row_label = torch.repeat_interleave(torch.arange(len(nx), device=dev), torch.as_tensor(nx, device=dev))
+            self.col_label = torch.repeat_interleave(torch.arange(len(ny), device=dev), torch.as_tensor(ny, device=dev))
+            self.groups = _plan_groups(np.asarray(keep, bool), nx, ny, _FINE_BUDGET)
+            self.y2 = (y * y).sum(1)
 
 
-def _block_rows(eps, Cobj, h, p, fn):
-    """Applies ``fn(rows r0:r1, column selector or None)`` over the row clusters of a (possibly truncated) fine cost."""
-    if Cobj.keep is None:
-        return fn(slice(0, Cobj.x.shape[0]), None)
-    keep = torch.as_tensor(Cobj.keep, device=Cobj.x.device)
-    outs = []
-    for k, (r0, r1) in enumerate(Cobj.ranges_x):
-        cols = keep[k][Cobj.col_label].nonzero().view(-1)
-        outs.append(fn(slice(int(r0), int(r1)), cols))
-    return outs
+def _fine_reduce(eps, Cobj, h, p, g=None):
+    """Block-sparse reduction over the kept (row cluster, column cluster) pairs, a run of row clusters at a time, all on the
+    device: soft-min values (N,) or, with ``g``, the gradient g_i sum_j P_ij dC/dx (N, D).  Rows without a kept column:
+    +inf (the soft-min of the empty set) / zero gradient."""
+    x, y = Cobj.x, Cobj.y
+    out = torch.empty(x.shape[0] if g is None else x.shape, dtype=F64, device=x.device)
+    inv_eps = 1.0 / eps
+    for k0, k1 in Cobj.groups:
+        r0, r1 = int(Cobj.ranges_x[k0, 0]), int(Cobj.ranges_x[k1 - 1, 1])
+        if r1 <= r0:
+            continue
+        cols = Cobj.keep[k0:k1].any(0)[Cobj.col_label].nonzero().view(-1)
+        if cols.numel() == 0:
+            out[r0:r1] = float("inf") if g is None else 0.0
+            continue
+        yc, hc, y2c, cl = y[cols], h[cols], Cobj.y2[cols], Cobj.col_label[cols]
+        for i0, i1 in _chunks(r1 - r0, cols.numel(), _FINE_BUDGET):
+            i0, i1 = r0 + i0, r0 + i1
+            xb = x[i0:i1]
+            E, row = _exponent(xb, yc, y2c, hc, inv_eps, p, exact=(p != 2))
+            E.masked_fill_(~Cobj.keep[Cobj.row_label[i0:i1]][:, cl], float("-inf"))
+            if g is None:
+                lse = torch.logsumexp(E, dim=1)
+                out[i0:i1] = -eps * (lse if row is None else lse + row)
+                continue
+            P = torch.nan_to_num(torch.softmax(E, dim=1), nan=0.0)       # a row with no kept column has no plan
+            if p == 2:
+                out[i0:i1] = g[i0:i1, None] * (xb * P.sum(1, keepdim=True) - P @ yc)
+            else:
+                acc = torch.zeros_like(xb)
+                d2 = torch.zeros_like(P)
+                for d in range(xb.shape[1]):
+                    diff = xb[:, d:d + 1] - yc[:, d].unsqueeze(0)
+                    d2 += diff * diff
+                W = P * torch.where(d2 > 1e-8, d2.clamp_min(1e-300).rsqrt(), torch.zeros_like(d2))
+                for d in range(xb.shape[1]):
+                    acc[:, d] = (W * (xb[:, d:d + 1] - yc[:, d].unsqueeze(0))).sum(1)
+                out[i0:i1] = g[i0:i1, None] * acc
+    return out
 
 
 def _softmin_obj(eps, Cobj, h, p, device):
     if isinstance(Cobj, dict):                      # coarse level: dense NumPy matrices of oracle_np
         return oracle_np.softmin_dense(eps, Cobj["C"], h)
-    ht = _t(h, device)
-
-    def fn(rows, cols):
-        if cols is None:
-            return softmin(eps, Cobj.x[rows], Cobj.y, ht, p=p, device=device)
-        if cols.numel() == 0:
-            return np.full(rows.stop - rows.start, np.inf)
-        return softmin(eps, Cobj.x[rows], Cobj.y[cols], ht[cols], p=p, device=device)
-
-    out = _block_rows(eps, Cobj, h, p, fn)
-    return out if isinstance(out, np.ndarray) else np.concatenate(out)
+    if Cobj.keep is None:
+        return softmin(eps, Cobj.x, Cobj.y, h, p=p, device=device)
+    return _np(_fine_reduce(eps, Cobj, _t(h, device).reshape(-1), p))
 
 
 def _softmin_grad_obj(eps, Cobj, h, g, p, device):
-    ht, gt = _t(h, device), _t(g, device)
-
-    def fn(rows, cols):
-        if cols is None:
-            return softmin_grad_x(eps, Cobj.x[rows], Cobj.y, ht, gt[rows], p=p, device=device)
-        return softmin_grad_x(eps, Cobj.x[rows], Cobj.y[cols], ht[cols], gt[rows], p=p, device=device)
-
-    out = _block_rows(eps, Cobj, h, p, fn)
-    return out if isinstance(out, np.ndarray) else np.concatenate(out)
+    if Cobj.keep is None:
+        return softmin_grad_x(eps, Cobj.x, Cobj.y, h, g, p=p, device=device)
+    return _np(_fine_reduce(eps, Cobj, _t(h, device).reshape(-1), p, g=_t(g, device).reshape(-1)))
 
 
 def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5, cluster_scale=None,
-                        debias=True, potentials=False, grad=False, device=None, return_info=False):
+                        debias=True, potentials=False, grad=False, full=False, device=None, return_info=False):
     """``SamplesLoss("sinkhorn", backend="multiscale")`` for one pair of clouds at any size: the coarse level on dense NumPy
-    matrices exactly as ``oracle_np.sinkhorn_multiscale`` (C ~ 2e3 clusters), the fine level cluster by cluster on the device."""
+    matrices exactly as ``oracle_np.sinkhorn_multiscale`` (C ~ 2e3 clusters), the fine level on the device, a run of row
+    clusters at a time (``_fine_reduce``).  ``full``: loss, dL/dx and the potentials (caller's point order) from ONE run of the
+    loop, as a dict."""
     device = default_device() if device is None else device
     a, x, b, y = (_host64(t) for t in (a, x, b, y))
     N, D = x.shape
@@ -312,7 +362,10 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
         if cluster_scale**p > e:
             jumps = [i + 1]
             break
-    xt, yt = _t(x, device), _t(y, device)
+    # one common frame for everything that reaches the device: the expanded squared distance of _exponent then acts on offsets
+    # of at most one diameter (float64: ~1e-16 diam^2 / eps on an exponent)
+    centre = 0.5 * (x.mean(0, keepdims=True) + y.mean(0, keepdims=True))
+    xt, yt = _t(x - centre, device), _t(y - centre, device)
     info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), kept_fraction=[], eps_list=eps_list)
 
     def coarse(u, v, ru, rv):
@@ -334,8 +387,9 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
 
     def extrapolate(f, g, eps_, lam, C_xy, b_log, C_xy_f):                       # :533-544
         h = b_log + g / eps_
-        extrapolations.append((eps_, C_xy_f.x, _t(C_xy["y"], device), h))
-        return lam * softmin(eps_, C_xy_f.x, C_xy["y"], h, p=p, device=device)
+        yc = _t(C_xy["y"] - centre, device)                                      # coarse cloud, in the frame of the fine one
+        extrapolations.append((eps_, C_xy_f.x, yc, h))
+        return lam * softmin(eps_, C_xy_f.x, yc, h, p=p, device=device)
 
     C_xys = [coarse(x_c, y_c, ranges_x, ranges_y), _FineCost(xt, yt, ranges_x, ranges_y)]
     C_yxs = [coarse(y_c, x_c, ranges_y, ranges_x), _FineCost(yt, xt, ranges_y, ranges_x)]
@@ -346,16 +400,19 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
                                          jumps=jumps, kernel_truncation=kernel_truncation, truncate=truncate,
                                          extrapolate=extrapolate, debias=debias)
     f_aa, g_bb, g_ab, f_ba = pots
-    out = oracle_np.sinkhorn_cost(eps_cost, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials)
-    if potentials:
-        F, G = out
+    out = oracle_np.sinkhorn_cost(eps_cost, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=potentials and not full)
+
+    def unsort(F, G):
         f_x, g_y = np.empty_like(F), np.empty_like(G)
         f_x[perm_x], g_y[perm_y] = F, G
-        out = (f_x, g_y)
+        return f_x, g_y
+
+    if potentials and not full:
+        out = unsort(*out)
     else:
         out = float(out)
-    if grad:
-        assert rho is None and not potentials
+    if grad or full:
+        assert rho is None and (full or not potentials)
         if "h_ba" in last:
             gs = _softmin_grad_obj(last["eps"], last["C_xy"], last["h_ba"], a, p, device)
             if debias:
@@ -368,5 +425,10 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
                 gs = gs - softmin_grad_x(e, xf, xc, h, a, p=p, device=device)
         gx = np.empty_like(gs)
         gx[perm_x] = gs
-        out = (out, gx)
+        if full:
+            F, G = unsort(*oracle_np.sinkhorn_cost(eps_cost, rho, a, b, f_aa, g_bb, g_ab, f_ba, debias=debias, potentials=True))
+            raw = max(np.abs(f_ba).max(), np.abs(g_ab).max())                    # scale of the raw dual values
+            out = dict(loss=out, gx=gx, F=F, G=G, dual_scale=float(raw), info=info)
+        else:
+            out = (out, gx)
     return (out, info) if return_info else out

@@ -231,8 +231,7 @@ def test_block_sparse_fwd_bwd_1e6_with_real_truncation_ranges(cuda):
 @pytest.mark.parametrize("N", [200_000])
 def test_cfg3_multiscale_end_to_end_vs_two_scale_oracle(cuda, N):
     """BASELINE configs[2] end to end — clustering, coarse loop, kernel truncation, extrapolation, truncated fine loop — against
-    the float64 two-scale oracle (fine level cluster by cluster on the GPU), at a size the oracle finishes in seconds.  The same
-    comparison at N = M = 1e6 (2 minutes of float64 work) is `tools/verify_cfg3.py`; its output is profiles/r02_cfg3_parity.txt."""
+    the float64 two-scale oracle, at a size the oracle finishes in seconds (the stated size, 1e6: the test below)."""
     x, y = _uniform_clouds(23, N, N, cuda, shift=True)
     kw = dict(p=2, blur=0.05)
     a = np.full(N, 1.0 / N)
@@ -243,6 +242,57 @@ def test_cfg3_multiscale_end_to_end_vs_two_scale_oracle(cuda, N):
     e = (abs(L.item() - ref) / abs(ref), relerr(gx.cpu().numpy(), ref_gx))
     print(f"cfg3 N={N}: loss {L.item():.9e} oracle {ref:.9e} rel {e[0]:.2e}; dL/dx rel {e[1]:.2e}; kept {info['kept_fraction']}")
     assert 0 < info["kept_fraction"][0] < 1 and info["jumps"][0] < len(info["eps_list"]) - 1
+    assert e[0] < 1e-4 and e[1] < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["shift", "same"])
+def test_cfg3_multiscale_1e6_end_to_end(cuda, kind):
+    """BASELINE configs[2] at its stated size, N = M = 1e6: device cluster pyramid, fused coarse loop, kernel truncation,
+    extrapolation, block-sparse fine loop, one-pass final update — loss, dL/dx and potentials against ONE run of the float64
+    two-scale oracle (fine level in runs of row clusters on this GPU: ~2.4e12 float64 pair evaluations).
+    ``shift``: a transport problem (y = 0.6 y + 0.3), everything at 1e-4.  ``same``: the config as benchmarked — two samples of
+    one law, whose loss (2.5e-6) is what is left of dual terms of size 0.1: potentials and gradient are asserted on their own
+    scale, the loss on the scale of the dual values it is a difference of; its relative error is reported."""
+    N = 1_000_000
+    x, y = _uniform_clouds(1, N, N, cuda, shift=(kind == "shift"))
+    kw = dict(p=2, blur=0.05)
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(xg, y)
+    (gx,) = torch.autograd.grad(L, [xg])
+    F, G = SamplesLoss("sinkhorn", backend="multiscale", potentials=True, **kw)(x, y)
+    L, gx, F, G = L.item(), gx.cpu().numpy(), F.cpu().numpy(), G.cpu().numpy()
+    torch.cuda.empty_cache()
+    a = np.full(N, 1.0 / N)
+    ref = o64.sinkhorn_multiscale(a, x, a, y, full=True, device=cuda, **kw)
+    info = ref["info"]
+    e_L = abs(L - ref["loss"])
+    e_g = relerr(gx, ref["gx"])
+    e_F = max(np.abs(F - ref["F"]).max(), np.abs(G - ref["G"]).max())
+    print(f"cfg3 1e6 {kind}: loss {L:.9e} oracle {ref['loss']:.9e} rel {e_L / abs(ref['loss']):.2e} (abs {e_L:.2e}, dual scale "
+          f"{ref['dual_scale']:.2e}); dL/dx rel {e_g:.2e}; potentials abs {e_F:.2e}; clusters {info['n_clusters']}, jump {info['jumps']}, "
+          f"kept {[round(k, 4) for k in info['kept_fraction']]}")
+    assert 0 < info["kept_fraction"][0] < 0.6 and info["jumps"][0] < len(info["eps_list"]) - 1
+    assert e_F < 1e-4 * ref["dual_scale"]
+    assert e_g < 1e-4
+    if kind == "shift":
+        assert e_L < 1e-4 * abs(ref["loss"])
+    else:
+        assert e_L < 1e-4 * ref["dual_scale"]          # the relative error of this 2.5e-6 residue is in the line printed above
+
+
+def test_cfg5_gaussian_mmd_1e6_loss_and_gradient(cuda):
+    """BASELINE configs[4] at its stated size: SamplesLoss("gaussian", blur=.05, backend="online"), N = M = 1e6, loss and dL/dx
+    against five float64 reductions of 1e12 pairs each.  Two samples of one law: the loss is 1e-6 of its three terms."""
+    N = 1_000_000
+    x, y = _uniform_clouds(13, N, N, cuda)
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss("gaussian", blur=0.05, backend="online")(xg, y)
+    (gx,) = torch.autograd.grad(L, [xg])
+    L, gx = L.item(), gx.cpu().numpy()
+    torch.cuda.empty_cache()
+    ref, rgx, _ = o64.kernel_loss("gaussian", x, y, blur=0.05, grad=True, device=cuda, budget=1 << 28)
+    e = (abs(L - ref) / abs(ref), relerr(gx, rgx))
+    print(f"cfg5 1e6: loss {L:.9e} oracle {ref:.9e} rel {e[0]:.2e}; dL/dx rel {e[1]:.2e}")
     assert e[0] < 1e-4 and e[1] < 1e-4
 
 

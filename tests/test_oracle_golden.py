@@ -186,3 +186,26 @@ def test_torch64_two_scale_oracle_equals_the_dense_masked_one():
         F, G = oracle_np.sinkhorn_multiscale(a, x, b, y, potentials=True, **kw)
         F2, G2 = oracle_torch64.sinkhorn_multiscale(a, x, b, y, potentials=True, device=CPU, **kw)
         assert np.abs(F - F2).max() < 1e-12 and np.abs(G - G2).max() < 1e-12
+        full = oracle_torch64.sinkhorn_multiscale(a, x, b, y, full=True, device=CPU, **kw)      # everything from one run
+        assert full["loss"] == r2 and np.array_equal(full["gx"], g2) and np.array_equal(full["F"], F2) and np.array_equal(full["G"], G2)
+
+
+@pytest.mark.parametrize("budget", [1 << 27, 40_000, 3_000])
+@pytest.mark.parametrize("p", [2, 1])
+def test_torch64_fine_level_runs_of_clusters(monkeypatch, budget, p):
+    """The batched fine level (runs of consecutive row clusters against the union of their kept columns, foreign pairs masked
+    out again) reduces over exactly the kept pair set whatever the grouping: one run for everything, a few clusters per run,
+    and runs so small that a single cluster is cut into row chunks — all equal to the dense masked oracle."""
+    monkeypatch.setattr(oracle_torch64, "_FINE_BUDGET", budget)
+    rng = np.random.default_rng(5)
+    N, M = 500, 450
+    x, y = rng.random((N, 3)), rng.random((M, 3)) * 0.7 + 0.2
+    a, b = rng.random(N) + 0.5, rng.random(M) + 0.5
+    a, b = a / a.sum(), b / b.sum()
+    kw = dict(p=2, blur=0.05, scaling=0.7, truncate=2, cluster_scale=0.15) if p == 2 else dict(p=1, blur=0.02, scaling=0.7, truncate=1, cluster_scale=0.1)
+    (r, g), i1 = oracle_np.sinkhorn_multiscale(a, x, b, y, grad=True, return_info=True, **kw)
+    full = oracle_torch64.sinkhorn_multiscale(a, x, b, y, full=True, device=CPU, **kw)
+    assert 0 < i1["kept_fraction"][0] < 0.9 and np.allclose(i1["kept_fraction"], full["info"]["kept_fraction"], rtol=1e-12)
+    assert abs(r - full["loss"]) <= 1e-11 * abs(r) and relerr(full["gx"], g) < 1e-10
+    F, G = oracle_np.sinkhorn_multiscale(a, x, b, y, potentials=True, **kw)
+    assert np.abs(F - full["F"]).max() < 1e-12 and np.abs(G - full["G"]).max() < 1e-12
