@@ -161,6 +161,14 @@ def hot_path_kernels(dev, n=1_000_000):
     add("laplacian_product", fresh(lambda: hip.kernel_conv("laplacian", x2, y2, v1, blur)), reps=2)
     add("energy_product", fresh(lambda: hip.kernel_conv("energy", x2, y2, v1, blur)), reps=2)
     add("softmin_fwd_p1_direct_differences", lambda: hip.softmin_fwd_raw(x, y, h, 0.05, 1), reps=1)
+    # 4 <= D <= 16: the same bf16x3 exponent as a chain of ceil((D + 1) / 2) MFMAs (csrc/glhip_softmin_xd.h)
+    gd = torch.Generator().manual_seed(11)
+    for D in (4, 5, 8, 16):
+        xd = torch.rand(1, n, D, generator=gd).to(dev)
+        yd = torch.rand(1, n, D, generator=gd).to(dev)
+        add(f"softmin_fwd_p2_d{D}", lambda: hip.softmin_fwd_raw(xd, yd, h, eps, 2), reps=2)
+        if D == 4:
+            add("gaussian_product_d4", lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, xd, yd, v, 2 * blur), reps=2)
     return res
 
 
@@ -215,6 +223,26 @@ def sinkhorn_wallclock(dev):
     run("gaussian_online_1e6_fwd_bwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, True, reps=1)
     run("energy_online_1e6_fwd_bwd", SamplesLoss("energy", backend="online"), 1_000_000, True, reps=1)
     run("gaussian_multiscale_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="multiscale"), 1_000_000, False, reps=1)
+
+    # the reference's recipe in dimension > 3 (examples/sinkhorn_multiscale/plot_optimal_transport_cluster.py:155-166): clusters given
+    # as labels — voxels of the 3 spatial coordinates of (position, feature) points — and the two-scale solver on the 4-D clouds
+    def labels4d(t, scale=0.08):
+        q = (t[:, :3] / scale).floor().long()
+        return torch.unique((q[:, 0] * 64 + q[:, 1]) * 64 + q[:, 2], return_inverse=True)[1].int()     # compact 0..C-1, like grid_cluster
+
+    g = torch.Generator().manual_seed(3)
+    x4, y4 = torch.rand(200_000, 4, generator=g).to(dev), torch.rand(200_000, 4, generator=g).to(dev)
+    loss4 = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")
+    w4 = torch.full((200_000,), 1.0 / 200_000, device=dev)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L = loss4(labels4d(x4), w4, x4, labels4d(y4), w4, y4)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    out["multiscale_4d_labels_2e5_fwd"] = {"seconds": min(ts[1:]), "first_call_seconds": ts[0], "loss": float(L)}
+    log(f"[bench] multiscale_4d_labels_2e5_fwd: {min(ts[1:]):.4f} s")
     return out
 
 

@@ -11,7 +11,20 @@ extern "C" {
 int glhip_version(void) { return GLHIP_VERSION; }
 
 size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
-    if (B <= 0 || N <= 0 || M <= 0 || D < 1 || D > 3) return 0;   // the generic-D kernels do not split
+    if (B <= 0 || N <= 0 || M <= 0 || D < 1 || D > kXdMaxD) return 0;   // the generic-D kernels (D > 16) do not split
+    if (D > 3) {   // 4 <= D <= 16 (glhip_softmin_xd.h): split partials of 2 floats per row, no packed columns
+        const int ns128 = choose_splits(n_ranges > 0 ? n_ranges : (long)B * ((N + 127) / 128), M, n_ranges, 1L << 30);
+        int nf = ns128;
+        if (n_ranges == 0 && M >= 65536) {
+            for (int rows = 256; rows <= 512; rows *= 2) {
+                const int nx = xcd_splits((long)B * ((N + rows - 1) / rows), M, kXdSlots, 32);
+                nf = nf > nx ? nf : nx;
+            }
+        }
+        size_t bytes = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float);
+        if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);
+        return bytes;
+    }
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
     const int ns = choose_splits(row_blocks, M, n_ranges, 1L << 30);
     size_t bytes = ns < 2 ? 0 : (size_t)ns * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);   // widest partial: D + 1 floats

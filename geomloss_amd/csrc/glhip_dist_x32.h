@@ -61,8 +61,11 @@ __device__ __forceinline__ float unpack_y(const uint4& r) {
 // bits to the cancellation |xs|^2 + |ys|^2 - 2 xs.ys; such pairs are rare (1024 pi/3 (1/16)^3 (R/L)^3 per block for clouds of
 // size L: ~0.4 % of the blocks at R/L = 0.1) and are recomputed here on explicit differences of the coordinates kept in LDS.
 // Register k of lane l holds column (k/4)*8 + (l/32)*4 + k%4 of the group (32x32 MFMA result layout).
+// The exact value is floored at clamp2 here (utils.py:61), so that the main loop can take square roots without a clamp: every
+// squared distance it sees is either >= thr >= clamp2 as computed, or exact and floored.
 template <int D>
-__device__ __forceinline__ void exact_near_pairs(f32x16& d2, float thr, const uint4* __restrict__ group, const float (&xs)[3], int half) {
+__device__ __forceinline__ void exact_near_pairs(f32x16& d2, float thr, float clamp2, const uint4* __restrict__ group, const float (&xs)[3],
+                                                 int half) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (d2[k] < thr) {
@@ -73,7 +76,7 @@ __device__ __forceinline__ void exact_near_pairs(f32x16& d2, float thr, const ui
                 const float df = xs[d] - unpack_y(group[d * 32 + col]);
                 e = __builtin_fmaf(df, df, e);
             }
-            d2[k] = e;
+            d2[k] = fmaxf(e, clamp2);
         }
     }
 }
@@ -85,13 +88,20 @@ __device__ __forceinline__ float min16(const f32x16& v) {
 }
 
 // reduction of one 32 x 32 block: d2 (scaled squared distances), sb (per-column scalar, minus the running max for the soft-min)
-template <int MODE>
+// CLAMP = false: the caller guarantees d2 >= clamp2 (see the near-pair logic of the kernel): |d2| only guards the square root
+// against a stray negative rounding residue (the absolute value is a free source modifier)
+template <bool CLAMP>
+__device__ __forceinline__ float dist_of(float d2, float clamp2) {
+    // v_med3_f32: the clamp in ONE instruction (fmaxf costs two: the compiler canonicalises the MFMA result first)
+    return CLAMP ? fast_sqrt(__builtin_amdgcn_fmed3f(d2, clamp2, 3.0e38f)) : fast_sqrt(__builtin_fabsf(d2));
+}
+
+template <int MODE, bool CLAMP = true>
 __device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, float clamp2) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        // v_med3_f32: the clamp in ONE instruction (fmaxf costs two: the compiler canonicalises the MFMA result first)
-        const float dist = fast_sqrt(__builtin_amdgcn_fmed3f(d2[k], clamp2, 3.0e38f));
+        const float dist = dist_of<CLAMP>(d2[k], clamp2);
         if (MODE == DM_SOFTMIN_P1) acc[k & 3] += fast_exp2(sb[k] - dist);
         else if (MODE == DM_LAPLACIAN) acc[k & 3] = __builtin_fmaf(fast_exp2(-dist), sb[k], acc[k & 3]);
         else acc[k & 3] = __builtin_fmaf(-dist, sb[k], acc[k & 3]);
@@ -102,7 +112,7 @@ __device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, f
 // kernel products: the per-column weight read straight from LDS (4 broadcast ds_read_b128 per block) instead of a third MFMA —
 // 16 result registers and one operand less, which is what lets 8 waves per SIMD fit (<= 64 VGPRs; 4 records + 4 bytes per column
 // = 34 KiB of LDS per workgroup).  sg = &weights[first column of the group + 4 * half]: register k <-> column (k/4)*8 + 4*half + k%4.
-template <int MODE>
+template <int MODE, bool CLAMP = true>
 __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __restrict__ sg, float clamp2) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -111,7 +121,7 @@ __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __
         const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dist = fast_sqrt(__builtin_amdgcn_fmed3f(d2[q * 4 + r], clamp2, 3.0e38f));
+            const float dist = dist_of<CLAMP>(d2[q * 4 + r], clamp2);
             if (MODE == DM_LAPLACIAN) acc[r] = __builtin_fmaf(fast_exp2(-dist), sv[r], acc[r]);
             else acc[r] = __builtin_fmaf(-dist, sv[r], acc[r]);
         }
@@ -120,7 +130,7 @@ __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __
 }
 
 template <int MODE, int D, typename T, int NW>
-__global__ void __launch_bounds__(NW * 64, MODE == DM_SOFTMIN_P1 ? 1 : 8)     // kernel products: 8 waves per SIMD (<= 64 VGPRs)
+__global__ void __launch_bounds__(NW * 64, MODE == DM_SOFTMIN_P1 ? 6 : 8)     // kernel products: 8 waves per SIMD (<= 64 VGPRs); soft-min: 6 (<= 80)
 dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerBlock = NW * 32;
     constexpr int kThreads = NW * 64;
@@ -196,24 +206,28 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                 a[d] = -2.f * xs;
             }
             thr = prm.guard * n2;
+            thr = fmaxf(thr, prm.clamp2);                  // everything below the floor of utils.py:61 takes the exact path too
             const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : kZero, p2 = (D > 2) ? pack_a(a[2]) : kZero;
-            Xlo = half ? p1 : p0;
-            Xhi = half ? pack_negmax(-n2) : p2;            // block 3 carries + |xs|^2
-            Xs = half ? kZero : kOnes;                     // block 4: the scalar itself (soft-min: rewritten with the running max)
+            Xlo = select_u4(half != 0, p1, p0);
+            Xhi = select_u4(half != 0, pack_negmax(-n2), p2);   // block 3 carries + |xs|^2
+            Xs = select_u4(half != 0, kZero, kOnes);            // block 4: the scalar itself (soft-min: rewritten with the running max)
         }
         // a column can only be a "near" partner (d < R_i / 16) of some row of this pass if it lies within 17/16 of the largest row
         // offset from the centre: tiles without such a column (nearly all of them once the columns are spatially sorted too) skip
         // the near-pair test altogether
         float near2;
         {
-            float r2 = wave_active ? thr : 0.f;
+            float r2 = wave_active ? prm.guard * xs3[0] * xs3[0] + prm.guard * (xs3[1] * xs3[1] + xs3[2] * xs3[2]) : 0.f;   // guard |xs|^2
             for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
             __syncthreads();
             if (lane == 0) csum[wave][3] = r2;
             __syncthreads();
             float tot = 0.f;
             for (int w = 0; w < NW; ++w) tot = fmaxf(tot, csum[w][3]);
-            near2 = (prm.guard > 0.f) ? tot / prm.guard * 1.13f : -1.f;     // thr = guard |xs|^2  ->  |xs|^2_max (17/16)^2
+            // thr = max(guard |xs|^2, clamp2).  A column within 17/16 of the largest row offset — or within the clamp radius of it —
+            // may form a pair below thr; every other tile is far enough for its squared distances to be >= 4 clamp2 as computed
+            const float rmax = fast_sqrt(tot / fmaxf(prm.guard, 1e-30f)), reach = 1.07f * rmax + 2.f * fast_sqrt(prm.clamp2);
+            near2 = (prm.guard > 0.f) ? reach * reach : -1.f;
         }
         float m = kMinusHuge, ssum = 0.f;                  // soft-min: lazy running max and sum;  products: ssum only
         bool first_group = true;
@@ -258,46 +272,52 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     const uint4* g = &tile[0];
                     f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                     d2 = mfma_x32(g[64 + rec0], Xhi, d2);
-                    if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
-                    const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
+                    if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, prm.clamp2, g, xs3, half);
+                    const f32x16 sb = mfma_x32(select_u4(half != 0, kZero, g[128 + l31]), Xs, zero16);
                     float um = kMinusHuge;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) um = fmaxf(um, sb[k] - fast_sqrt(__builtin_amdgcn_fmed3f(d2[k], prm.clamp2, 3.0e38f)));
                     um = fmaxf(um, __shfl_xor(um, 32, 64));
                     m = um;
-                    if (!half) Xs = pack_negmax(m);
-                    ssum = block_sum<MODE>(d2, mfma_x32(half ? kZero : g[128 + l31], Xs, zero16), prm.clamp2);
+                    Xs = select_u4(half == 0, pack_negmax(m), Xs);
+                    ssum = block_sum<MODE>(d2, mfma_x32(select_u4(half != 0, kZero, g[128 + l31]), Xs, zero16), prm.clamp2);
                     first_group = false;
                     G0 = 1;
                 }
-                auto main_loop = [&](auto guarded) {
+                // guarded: the tile may hold pairs below thr (near pairs, or pairs inside the clamp radius): test every block.
+                // clamped: only when the near-pair guard is switched off (GLHIP_DIST_GUARD=0), otherwise no squared distance that
+                // reaches the square root is below clamp2 (see exact_near_pairs) and the clamp instruction is dropped.
+                auto main_loop = [&](auto guarded, auto clamped) {
+                    constexpr bool CL = decltype(clamped)::value;
                     float st = 0.f;
                     for (int G = G0; G < nG; ++G) {
                         const uint4* g = &tile[G * (32 * REC)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
                         if constexpr (decltype(guarded)::value) {
-                            if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
+                            if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, prm.clamp2, g, xs3, half);
                         }
                         if constexpr (kWeightsInLds) {
-                            st += block_sum_lds<MODE>(d2, &weights[G * 32 + half * 4], prm.clamp2);
+                            st += block_sum_lds<MODE, CL>(d2, &weights[G * 32 + half * 4], prm.clamp2);
                         } else {
-                            const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], Xs, zero16);
-                            st += block_sum<MODE>(d2, sb, prm.clamp2);
+                            const f32x16 sb = mfma_x32(select_u4(half != 0, kZero, g[128 + l31]), Xs, zero16);
+                            st += block_sum<MODE, CL>(d2, sb, prm.clamp2);
                         }
                     }
                     return st;
                 };
-                const float stmp = tile_near ? main_loop(std::true_type{}) : main_loop(std::false_type{});
+                const float stmp = !(prm.guard > 0.f) ? main_loop(std::false_type{}, std::true_type{})
+                                   : tile_near        ? main_loop(std::true_type{}, std::false_type{})
+                                                      : main_loop(std::false_type{}, std::false_type{});
                 if (MODE == DM_SOFTMIN_P1 && __any(!(stmp < kSumThr))) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
-                    const uint4 plain = half ? kZero : kOnes;
+                    const uint4 plain = select_u4(half != 0, kZero, kOnes);
                     for (int G = G0; G < nG; ++G) {
                         const uint4* g = &tile[G * (32 * REC)];
                         f32x16 d2 = mfma_x32(g[rec0], Xlo, zero16);
                         d2 = mfma_x32(g[64 + rec0], Xhi, d2);
-                        if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, g, xs3, half);
-                        const f32x16 sb = mfma_x32(half ? kZero : g[128 + l31], plain, zero16);
+                        if (tile_near && __any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, prm.clamp2, g, xs3, half);
+                        const f32x16 sb = mfma_x32(select_u4(half != 0, kZero, g[128 + l31]), plain, zero16);
                         float u[16], um = kMinusHuge;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
@@ -312,7 +332,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         ssum = ssum * fast_exp2(m - mnew) + s2;
                         m = mnew;
                     }
-                    if (!half) Xs = pack_negmax(m);
+                    Xs = select_u4(half == 0, pack_negmax(m), Xs);
                 } else {
                     ssum += stmp;
                 }

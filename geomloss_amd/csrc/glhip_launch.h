@@ -17,6 +17,7 @@
 #include "glhip_softmin_x32.h"
 #include "glhip_wsum_x32.h"
 #include "glhip_dist_x32.h"
+#include "glhip_softmin_xd.h"
 
 using namespace glhip;
 
@@ -318,6 +319,73 @@ void launch_dist(const DistParams<T>& prm, const typename MergeOp::Params& mprm,
         hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
 }
 
+// ---- 4 <= D <= 16 on the matrix cores (glhip_softmin_xd.h): soft-min forward / fused half-step (MODE XD_SOFTMIN) and gaussian
+// product (XD_GAUSS).  Column splits, XCD-aware 1-D grid for big dense launches, row chunks for block-sparse ones and the merge
+// kernels are those of the D <= 3 kernels; there is no pre-packed column copy.
+constexpr int kXdMaxD = 16;
+constexpr long kXdSlots = 256 * 2;    // resident 8-wave workgroups (<= 48 KiB of LDS, <= 128 VGPRs)
+
+template <int MODE, int D, typename T, class MergeOp, int RT, int NW>
+void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
+                   int M, const Scratch& sc, hipStream_t st) {
+    constexpr int kPart = MODE == XD_SOFTMIN ? 2 : 1;
+    static_assert(MergeOp::kPartial == kPart, "partial formats differ");
+    static_assert(MergeOp::kRows == 1, "the merge launch below tiles rows in blocks of kBlock");
+    constexpr int kRows = RT * NW * 32;
+    unsigned chunk_grid = 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRows, sc.cb, st, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kRows - 1) / kRows);
+    const long per_split = (long)B * N * kPart * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * kPart;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    const int gx = (N + kRows - 1) / kRows;
+    const dim3 merge_grid((N + kBlock - 1) / kBlock, B, 1);
+    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD at a time (workgroup_coords)
+        const int nx = xcd_splits((long)gx * B, M, kXdSlots, fit);
+        const long total = (long)gx * B * nx;
+        if (total < (1L << 31)) {
+            sp.n_splits = nx;
+            sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
+            hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
+            return;
+        }
+    }
+    if (n_ranges > 0) {
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, true, RT, NW>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+    } else {
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
+    }
+}
+
+template <int MODE, int D, typename T, class MergeOp>
+void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N, int M,
+               const Scratch& sc, hipStream_t st) {
+    // big launches: 8 wavefronts x 2 row tiles (512 rows share the bf16 pieces of a column; 1 tile from D = 9 up, where the
+    // x-side operands of two tiles would not fit 128 VGPRs); small ones: 4 wavefronts x 1 tile, more workgroups
+    const bool big = (double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192);
+    if (big) launch_xd_cfg<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    else launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+}
+
+#define GLHIP_XD_DISPATCH(D, CALL)                                                                                        \
+    switch (D) {                                                                                                          \
+        case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;              \
+        case 8: CALL(8); break;   case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break;            \
+        case 12: CALL(12); break; case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break;            \
+        default: CALL(16); break;                                                                                         \
+    }
+
 inline bool use_mfma_dist(int flags, int n_ranges, int B, int D) {
     return (flags & GLHIP_FLAG_MFMA_DIST) != 0 && n_ranges > 0 && B == 1 && D <= 3;
 }
@@ -464,8 +532,18 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
     } else {
+        if constexpr (!BWD) {
+            if (p == 2 && D <= kXdMaxD && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // 4 <= D <= 16: matrix cores
+                SoftminParams<T> prm = make_softmin_params<T>(x, y, h, out, eps, 2, step.pot, step.prev, step.alpha, step.beta);
+#define GL_XD(DD) launch_xd<XD_SOFTMIN, DD, T, SoftminFwdOp<DD, 2, false, 1, T>>(prm, prm, rg, n_ranges, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
+        }
         if (step.pot || step.prev || step.alpha != 1.f)
-            return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: D=%d > 3 has no fused kernel (use glhip_softmin_fwd)", D);
+            return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: no fused kernel for D=%d, p=%d, flags=%d (D <= 16, p = 2 on the matrix "
+                                            "cores only): use glhip_softmin_fwd", D, p, flags);
         if (BWD && D > kGenericMaxGradD)
             return fail(GLHIP_EUNSUPPORTED, "softmin_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
                         D, kGenericMaxGradD);
@@ -593,6 +671,19 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             launch_conv_d<GLHIP_ENERGY, BWD, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         }
     } else {
+        if constexpr (!BWD) {
+            if (kind == GLHIP_GAUSSIAN && D <= kXdMaxD && !(flags & GLHIP_FLAG_NO_MFMA)) {   // 4 <= D <= 16: matrix cores
+                // the gaussian exponent -|x-y|^2 / (2 blur^2) is the soft-min's with eps = blur^2 and h = 0; `h` carries v
+                const SoftminParams<T> prm = make_softmin_params<T>(x, y, v, out, blur * blur, 2, nullptr, nullptr, 1.f, 0.f);
+                ConvParams<T> mprm;
+                mprm.x = prm.x; mprm.y = prm.y; mprm.v = v; mprm.out = out; mprm.g = nullptr; mprm.gx = nullptr;
+                mprm.t = 1.f; mprm.gscale = 0.f; mprm.clamp2 = 0.f;
+#define GL_XD(DD) launch_xd<XD_GAUSS, DD, T, ConvOp<GLHIP_GAUSSIAN, DD, 1, T, 0>>(prm, mprm, rg, n_ranges, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
+        }
         if (BWD && D > kGenericMaxGradD)
             return fail(GLHIP_EUNSUPPORTED, "kernel_conv_bwd_x: D=%d > %d is not supported by the generic gradient kernel",
                         D, kGenericMaxGradD);

@@ -43,6 +43,12 @@ __device__ __forceinline__ uint4 pack_negmax(float m) {
     return uint4{0x3F803F80u, 0x3F80u | (p1 << 16), p2 | (p3 << 16), 0u};
 }
 
+// lane-dependent choice between two 16-byte operands, field by field (a `?:` on the uint4 structs themselves is lowered through
+// scratch memory: both values stored, one re-loaded at a lane-dependent address)
+__device__ __forceinline__ uint4 select_u4(bool c, const uint4& a, const uint4& b) {
+    return uint4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
+}
+
 __device__ __forceinline__ float max16(const f32x16& v) {
     const float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
     const float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));

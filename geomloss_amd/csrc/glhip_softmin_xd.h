@@ -1,0 +1,277 @@
+// glhip_softmin_xd.h — the bf16x3 matrix-core reductions for clouds of dimension 4 <= D <= 16: soft-min forward (p = 2, incl. the
+// fused Sinkhorn half-step) and gaussian kernel product.
+//
+// Same arithmetic and the same transposed 32 x 32 blocks as glhip_softmin_x32.h (D <= 3): every fp32 operand is the exact sum of
+// three bf16 pieces, one coordinate fills one K block of 8 slots ([y1,y2,y1,y3,y1,y2,y3,y2] against [a1,a1,a2,a1,a3,a2,a2,a3]),
+// one more block carries the per-column scalar and the per-row constant ([H1,H2,H3,1,1,1,0,0] against [1,1,1,n1,n2,n3,0,0]).  A
+// v_mfma_f32_32x32x16_bf16 takes two K blocks (lanes 0-31 hold the even one, lanes 32-63 the odd one), so a block of exponents
+// is a chain of NM = ceil((D + 1) / 2) MFMAs instead of 2: 3 for D = 4, 5; 5 for D = 8; 9 for D = 16.  The VALU work per pair does
+// not depend on D — one v_exp_f32 and one v_add_f32 (soft-min) or v_fma_f32 (gaussian) — and a 32x32x16 MFMA costs 32 cycles of
+// matrix pipe per 1024 pairs against ~200 cycles of that VALU stream, so up to D ~ 10 the chain hides behind the exponentials;
+// beyond, the kernel becomes matrix-pipe bound (9 x 32 = 288 cycles per 1024 pairs at D = 16).
+//
+// The reference takes any D (`Vi({D})` in lse_genred, _legacy/sinkhorn_samples.py:322-334; its multiscale tutorial is 4-D:
+// examples/sinkhorn_multiscale/plot_optimal_transport_cluster.py:58-61); before this header every D >= 4 went to the
+// one-thread-per-row VALU kernel of glhip_generic.h (2 instructions per pair and dimension), which stays for D > 16, p = 1 and
+// the gradients.
+//
+// LDS: NBP = 2 NM records of 16 bytes per column (the last one is a zero pad when D + 1 is odd), tiles of 512 / 256 / 128 columns
+// (<= 48 KiB).  Columns are split into pieces when a tile is staged (no pre-packed copy: the pieces of one column serve RT x NW x 32
+// = 512 rows of the workgroup's pass on big launches, which amortises the ~13 VALU instructions per coordinate).
+#pragma once
+
+#include "glhip_softmin_x32.h"
+
+namespace glhip {
+
+enum XdMode { XD_SOFTMIN = 0, XD_GAUSS = 1 };
+
+template <int D>
+struct XdShape {
+    static_assert(D >= 4 && D <= 16, "glhip_softmin_xd.h serves 4 <= D <= 16");
+    static constexpr int NB = D + 1;                 // K blocks in use: D coordinates + the scalar block
+    static constexpr int NM = (NB + 1) / 2;          // chained MFMAs per 32 x 32 block
+    static constexpr int NBP = 2 * NM;               // records per column in LDS
+    static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);   // columns per LDS tile
+    static constexpr int HM = D / 2;                 // the scalar block is K block D: MFMA D / 2 ...
+    static constexpr int HH = D % 2;                 // ... lane half D % 2
+};
+
+// One column as NBP records `stride` apart starting at `base`; coordinates relative to `centre`.
+//   XD_SOFTMIN: H = log2(e) h_j - s/2 |yt|^2  (h_j through dual_entry: the fused half-step adds pot_j / eps)
+//   XD_GAUSS:   H = -s/2 |yt|^2, and the weight v_j = prm.h[col] goes to *vdst
+template <int MODE, int D, typename T>
+__device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long col, bool valid, const float (&centre)[D],
+                                               uint4* base, int stride, float* vdst) {
+    using S = XdShape<D>;
+    float yt[D];
+    float H = kNegBig, vj = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) yt[d] = 0.f;
+    if (valid) {
+        float yj[D];
+        load_point<D, T>(prm.y, col, yj);
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            yt[d] = yj[d] - centre[d];
+            n2 = __builtin_fmaf(yt[d], yt[d], n2);
+        }
+        if (MODE == XD_SOFTMIN) {
+            H = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, col) * kLog2e);
+        } else {
+            H = -0.5f * prm.s2 * n2;
+            vj = prm.h[col];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) base[d * stride] = pack_y(yt[d]);
+    base[D * stride] = pack_h1(H);
+    if (S::NBP > S::NB) base[S::NB * stride] = uint4{0u, 0u, 0u, 0u};
+    if (MODE == XD_GAUSS) *vdst = vj;
+}
+
+// the chained MFMAs of one 32 x 32 block: column group `g` (LDS) against the x-side operands X
+template <int NM, int NBP>
+__device__ __forceinline__ f32x16 xd_block(const uint4* __restrict__ g, int rec0, const uint4 (&X)[NM], const f32x16& zero16) {
+    f32x16 u = mfma_x32(g[rec0], X[0], zero16);
+#pragma unroll
+    for (int m = 1; m < NM; ++m) u = mfma_x32(g[m * 64 + rec0], X[m], u);
+    return u;
+}
+
+// sum_k 2^(u_k) v_k over the 16 registers of a block; register k <-> column (k / 4) * 8 + 4 * half + k % 4 of the group
+// (vg = &tileV[first column of the group + 4 * half]: four broadcast 16-byte reads)
+__device__ __forceinline__ float xd_weighted_sum(const f32x16& u, const float* __restrict__ vg) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v4 = *reinterpret_cast<const float4*>(vg + q * 8);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(fast_exp2(u[q * 4 + r]), vv[r], acc[r]);
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    using S = XdShape<D>;
+    constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
+    constexpr int kRowsPerWave = RT * 32;
+    constexpr int kRowsPerBlock = NW * kRowsPerWave;
+    constexpr int kThreads = NW * 64;
+    __shared__ uint4 tile[kTileD * NBP];                      // [column group of 32][K block 0..NBP-1][column]
+    __shared__ float tileV[MODE == XD_GAUSS ? kTileD : 4];    // gaussian: the weights v_j of the tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
+    const int ns = sp.n_splits;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int rec0 = half * 32 + l31;       // K block `half` of MFMA 0; MFMA m: + 64 m
+
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint4 kOnes = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // [1,1,1,0,...]: the scalar block with n = 0
+    const uint4 kZero = uint4{0u, 0u, 0u, 0u};
+    const bool owns_h = (half == S::HH);                          // this lane's half carries the scalar block in MFMA HM
+
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
+        float centre[D];
+        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+
+        const int wave_row0 = row0 + wave * kRowsPerWave;
+        const bool wave_active = wave_row0 < row_end;
+        uint4 X[RT][NM];
+        float m[RT], ssum[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int i = min(wave_row0 + rt * 32 + l31, row_end - 1);
+            float xi[D];
+            load_point<D, T>(prm.x, (long)b * N + i, xi);
+            float a[D], n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float xt = xi[d] - centre[d];
+                n2 = __builtin_fmaf(xt, xt, n2);
+                a[d] = xt * prm.s2;
+            }
+            // scalar block of the x side: [1,1,1,n1,n2,n3]; soft-min: n = -running max (0 until the first group has been seen),
+            // gaussian: n = r_i = -s/2 |xt_i|^2, constant
+            const uint4 hblk = (MODE == XD_SOFTMIN) ? kOnes : pack_negmax(0.5f * prm.s2 * n2);
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) {
+                const int kb0 = 2 * mm, kb1 = 2 * mm + 1;
+                // the coordinate this lane packs for MFMA mm (its half's K block), when that block is a coordinate
+                const float av = (kb1 < D) ? (half ? a[kb1 < D ? kb1 : 0] : a[kb0]) : a[kb0 < D ? kb0 : 0];
+                uint4 pa = pack_a(av);
+                if (kb0 == D) pa = hblk;                                  // D even: the scalar block sits in half 0 of the last MFMA
+                if (kb1 == D) pa = select_u4(half != 0, hblk, pa);        // D odd: in half 1
+                if (kb1 > D) pa = select_u4(half != 0, kZero, pa);        // D even: half 1 of the last MFMA is the zero pad
+                X[rt][mm] = pa;
+            }
+            m[rt] = kMinusHuge;
+            ssum[rt] = 0.f;
+        }
+        bool first_group = (MODE == XD_SOFTMIN);
+
+        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
+            int js, je;
+            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            for (int j0 = js; j0 < je; j0 += kTileD) {
+                const int n = min(kTileD, je - j0);
+                const int npad = (n + 31) & ~31;
+                __syncthreads();
+                for (int t = tid; t < npad; t += kThreads)
+                    pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tile[(t >> 5) * (32 * NBP) + (t & 31)], 32,
+                                               &tileV[MODE == XD_GAUSS ? t : 0]);
+                __syncthreads();
+                if (!wave_active) continue;
+
+                const int nG = npad / 32;
+                if (MODE == XD_GAUSS) {
+                    for (int G = 0; G < nG; ++G) {
+                        const uint4* g = &tile[G * (32 * NBP)];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            ssum[rt] += xd_weighted_sum(xd_block<NM, NBP>(g, rec0, X[rt], zero16), &tileV[G * 32 + half * 4]);
+                    }
+                    continue;
+                }
+
+                int G0 = 0;
+                if (first_group) {   // exact maximum over the first 32 columns
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x16 u = xd_block<NM, NBP>(&tile[0], rec0, X[rt], zero16);
+                        float um = max16(u);
+                        um = fmaxf(um, __shfl_xor(um, 32, 64));
+                        um = fmaxf(um, kMinusHuge);
+                        m[rt] = um;
+                        ssum[rt] = sum_exp2_16(u, um);
+                        X[rt][S::HM] = select_u4(owns_h, pack_negmax(um), X[rt][S::HM]);
+                    }
+                    first_group = false;
+                    G0 = 1;
+                }
+
+                float stmp[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
+                for (int G = G0; G < nG; ++G) {
+                    const uint4* g = &tile[G * (32 * NBP)];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(xd_block<NM, NBP>(g, rec0, X[rt], zero16));
+                }
+                float smax = stmp[0];
+#pragma unroll
+                for (int rt = 1; rt < RT; ++rt) smax = fmaxf(smax, stmp[rt]);
+                if (__any(!(smax < kSumThr))) {
+                    // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
+                    for (int G = G0; G < nG; ++G) {
+                        const uint4* g = &tile[G * (32 * NBP)];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            uint4 Xp[NM];
+#pragma unroll
+                            for (int mm = 0; mm < NM; ++mm) Xp[mm] = X[rt][mm];
+                            Xp[S::HM] = select_u4(owns_h, kOnes, Xp[S::HM]);              // n = 0: plain exponents
+                            const f32x16 u = xd_block<NM, NBP>(g, rec0, Xp, zero16);
+                            float um = max16(u);
+                            um = fmaxf(um, __shfl_xor(um, 32, 64));
+                            const float mnew = fmaxf(m[rt], um);
+                            ssum[rt] = ssum[rt] * fast_exp2(m[rt] - mnew) + sum_exp2_16(u, mnew);
+                            m[rt] = mnew;
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) X[rt][S::HM] = select_u4(owns_h, pack_negmax(m[rt]), X[rt][S::HM]);
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
+                }
+            }
+        }
+
+        if (wave_active) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // the halves hold the two 16-column halves of every block
+                const int i = wave_row0 + rt * 32 + l31;
+                if (half == 0 && i < row_end) {
+                    const long idx = (long)b * N + i;
+                    if (MODE == XD_GAUSS) {
+                        if (ns == 1) prm.out[idx] = s;
+                        else sp.workspace[split * sp.split_stride + idx] = s;
+                    } else {
+                        float xi[D];
+                        load_point<D, T>(prm.x, idx, xi);
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            const float xt = xi[d] - centre[d];
+                            n2 = __builtin_fmaf(xt, xt, n2);
+                        }
+                        const float mtot = __builtin_fmaf(-0.5f * prm.s2, n2, m[rt]);   // r_i + m
+                        if (ns == 1) {
+                            prm.out[idx] = finish_value(prm, idx, mtot + fast_log2(s));
+                        } else {
+                            float* dst = sp.workspace + split * sp.split_stride + idx * 2;
+                            dst[0] = mtot;
+                            dst[1] = s;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace glhip

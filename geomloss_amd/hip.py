@@ -22,6 +22,7 @@ KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
 FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST = 1, 2, 4, 8, 16, 32, 64
 FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
+XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussian product run on the matrix cores up to this dimension
 
 # every symbol include/glhip.h declares, with its ctypes signature
 _c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

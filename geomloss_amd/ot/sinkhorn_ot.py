@@ -187,8 +187,8 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
 
 
 def _averaged(eps, lam, rows, cols, log_w, pot, prev):
-    """(prev + lam * softmin(eps, C, log_w + pot/eps)) / 2 as one fused launch (D <= 3) or soft-min + torch arithmetic."""
-    if rows.shape[1] <= 3:
+    """(prev + lam * softmin(eps, C, log_w + pot/eps)) / 2 as one fused launch (D <= 16) or soft-min + torch arithmetic."""
+    if rows.shape[1] <= hip.XD_MAX_DIM:
         return hip.sinkhorn_step(eps, rows, cols, log_w, pot, prev, lam)
     return 0.5 * (prev + lam * hip.softmin(eps, rows, cols, log_w + pot / eps))
 

@@ -30,9 +30,20 @@ Pinning: ``tests/test_oracle_golden.py::test_torch64_*`` checks every function h
 import numpy as np
 import torch
 
-from . import oracle_np
+from . import oracle_hip64, oracle_np
 
 F64 = torch.float64
+# Reductions of >= HIP64_MIN_PAIRS pairs on a GPU go to the brute-force float64 HIP kernels of oracle_hip64.hip (explicit
+# differences, one thread per row: seconds where the chunked torch ops below need minutes).  tests/test_full_size_gpu.py pins
+# those kernels against this module's torch path and against oracle_c.c on the same box before relying on them.
+USE_HIP64 = True
+HIP64_MIN_PAIRS = 2e10
+
+
+def _hip64(device, N, M, D):
+    return (USE_HIP64 and torch.device(device).type == "cuda" and float(N) * M >= HIP64_MIN_PAIRS and D <= 16
+            and oracle_hip64.available())
+
 _BUDGET = 1 << 26   # matrix entries per chunk (512 MB in float64; a handful of temporaries live at once)
 
 
@@ -85,6 +96,8 @@ def softmin(eps, x, y, h, p=2, device=None, exact=False, rows=None, budget=_BUDG
     x, y, h = _t(x, device), _t(y, device), _t(h, device).reshape(-1)
     if rows is not None:
         x = x[torch.as_tensor(rows, device=device)]
+    if _hip64(device, x.shape[0], y.shape[0], x.shape[1]):
+        return _np(oracle_hip64.softmin(eps, x, y, h, p, device=device))
     x, y = _centred(x, y)
     y2 = (y * y).sum(1)
     out = torch.empty(x.shape[0], dtype=F64, device=device)
@@ -102,6 +115,8 @@ def softmin_grad_x(eps, x, y, h, g, p=2, device=None, rows=None, budget=_BUDGET)
     if rows is not None:
         sel = torch.as_tensor(rows, device=device)
         x, g = x[sel], g[sel]
+    if _hip64(device, x.shape[0], y.shape[0], x.shape[1]):
+        return _np(oracle_hip64.softmin_grad_x(eps, x, y, h, g, p, device=device))
     x, y = _centred(x, y)
     y2 = (y * y).sum(1)
     out = torch.empty_like(x)
@@ -158,6 +173,8 @@ def kconv(kind, x, y, v, blur=0.05, device=None, rows=None, budget=_BUDGET):
     x, y, v = _t(x, device), _t(y, device), _t(v, device).reshape(-1)
     if rows is not None:
         x = x[torch.as_tensor(rows, device=device)]
+    if _hip64(device, x.shape[0], y.shape[0], x.shape[1]):
+        return _np(oracle_hip64.kconv(kind, x, y, v, blur, device=device))
     x, y = _centred(x, y)
     out = torch.empty(x.shape[0], dtype=F64, device=device)
     for i0, i1 in _chunks(x.shape[0], y.shape[0], budget // 2):
@@ -173,6 +190,8 @@ def kconv_grad_x(kind, x, y, v, g, blur=0.05, device=None, rows=None, budget=_BU
     if rows is not None:
         sel = torch.as_tensor(rows, device=device)
         x, g = x[sel], g[sel]
+    if _hip64(device, x.shape[0], y.shape[0], x.shape[1]):
+        return _np(oracle_hip64.kconv(kind, x, y, v, blur, g=g, device=device, value=False)[1])
     x, y = _centred(x, y)
     out = torch.empty_like(x)
     for i0, i1 in _chunks(x.shape[0], y.shape[0], budget // 2):
@@ -283,8 +302,12 @@ class _FineCost:
             self.keep = torch.as_tensor(np.ascontiguousarray(keep), device=dev)
             self.row_label = torch.repeat_interleave(torch.arange(len(nx), device=dev), torch.as_tensor(nx, device=dev))
             self.col_label = torch.repeat_interleave(torch.arange(len(ny), device=dev), torch.as_tensor(ny, device=dev))
-            self.groups = _plan_groups(np.asarray(keep, bool), nx, ny, _FINE_BUDGET)
             self.y2 = (y * y).sum(1)
+            self.hip64 = _hip64(dev, x.shape[0], y.shape[0], x.shape[1])
+            if self.hip64:     # the kept blocks as CSR lists of column intervals for oracle_hip64.hip
+                self.pattern = oracle_hip64.make_pattern(keep, self.ranges_x, self.ranges_y, dev)
+            else:
+                self.groups = _plan_groups(np.asarray(keep, bool), nx, ny, _FINE_BUDGET)
 
 
 def _fine_reduce(eps, Cobj, h, p, g=None):
@@ -292,6 +315,10 @@ def _fine_reduce(eps, Cobj, h, p, g=None):
     device: soft-min values (N,) or, with ``g``, the gradient g_i sum_j P_ij dC/dx (N, D).  Rows without a kept column:
     +inf (the soft-min of the empty set) / zero gradient."""
     x, y = Cobj.x, Cobj.y
+    if Cobj.hip64:
+        if g is None:
+            return oracle_hip64.softmin(eps, x, y, h, p, pattern=Cobj.pattern, device=x.device)
+        return oracle_hip64.softmin_grad_x(eps, x, y, h, g, p, pattern=Cobj.pattern, device=x.device)
     out = torch.empty(x.shape[0] if g is None else x.shape, dtype=F64, device=x.device)
     inv_eps = 1.0 / eps
     for k0, k1 in Cobj.groups:

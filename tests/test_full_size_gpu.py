@@ -30,6 +30,78 @@ def _uniform_clouds(seed, N, M, dev, shift=False):
     return x.to(dev), y.to(dev)
 
 
+# ---- the float64 HIP oracle (oracle/oracle_hip64.hip) that the 1e6-point tests below rely on: pinned first ----------------------
+
+@pytest.mark.parametrize("D", [1, 2, 3, 5])
+@pytest.mark.parametrize("p", [2, 1])
+def test_hip64_oracle_pinned_to_the_c_oracle(cuda, D, p):
+    """oracle_hip64 (one GPU thread per row, explicit float64 differences) against oracle_c.c (the CPU restatement pinned to the
+    reference's golden vectors by tests/test_oracle_golden.py): soft-min, its gradient, the three kernel products and gradients,
+    dense and block-sparse, incl. a row cluster without columns and -inf dual values."""
+    from oracle import oracle_c, oracle_hip64
+    rng = np.random.default_rng(10 * D + p)
+    N, M = 700, 900
+    x, y = rng.random((N, D)), rng.random((M, D)) * 0.8 + 0.1
+    y[5] = x[7]                                             # a coincident pair: the clamp of utils.py:61
+    h, g = rng.standard_normal(M), rng.standard_normal(N)
+    h[11] = -np.inf
+    eps = 0.05 ** p
+    out = oracle_hip64.softmin(eps, x, y, h, p, device=cuda).cpu().numpy()
+    assert np.abs(out - oracle_c.softmin(eps, x, y, h, p)).max() < 1e-12
+    gx = oracle_hip64.softmin_grad_x(eps, x, y, h, g, p, device=cuda).cpu().numpy()
+    assert relerr(gx, oracle_c.softmin_grad_x(eps, x, y, h, g, p)) < 1e-11
+    v = rng.random(M) / M
+    for kind in ("gaussian", "laplacian", "energy"):
+        k, gk = oracle_hip64.kconv(kind, x, y, v, 0.2, g=g, device=cuda)
+        assert relerr(k.cpu().numpy(), oracle_c.kconv(kind, x, y, v, 0.2)) < 1e-12, kind
+        assert relerr(gk.cpu().numpy(), oracle_c.kconv_grad_x(kind, x, y, v, g, 0.2)) < 1e-11, kind
+    # block-sparse: 6 x 7 clusters, random keep mask with one empty row
+    ci, cj = 6, 7
+    cut = lambda n, c: np.r_[0, np.sort(rng.choice(np.arange(1, n), c - 1, replace=False)), n]      # noqa: E731
+    bi, bj = cut(N, ci), cut(M, cj)
+    ri, rj = np.stack([bi[:-1], bi[1:]], 1), np.stack([bj[:-1], bj[1:]], 1)
+    keep = rng.random((ci, cj)) < 0.5
+    keep[2, :] = False
+    pat = oracle_hip64.make_pattern(keep, ri, rj, cuda)
+    out = oracle_hip64.softmin(eps, x, y, h, p, pattern=pat, device=cuda).cpu().numpy()
+    gx = oracle_hip64.softmin_grad_x(eps, x, y, h, g, p, pattern=pat, device=cuda).cpu().numpy()
+    for k in range(ci):
+        rows = slice(ri[k, 0], ri[k, 1])
+        cols = np.concatenate([np.arange(rj[c, 0], rj[c, 1]) for c in range(cj) if keep[k, c]] + [np.zeros(0, int)]).astype(int)
+        if cols.size == 0:
+            assert np.isposinf(out[rows]).all() and (gx[rows] == 0).all()
+            continue
+        assert np.abs(out[rows] - oracle_c.softmin(eps, x[rows], y[cols], h[cols], p)).max() < 1e-12
+        assert relerr(gx[rows], oracle_c.softmin_grad_x(eps, x[rows], y[cols], h[cols], g[rows], p)) < 1e-11
+
+
+def test_hip64_oracle_equals_the_torch_path_at_mid_size(cuda, monkeypatch):
+    """The two float64 evaluations of oracle_torch64 — chunked torch ops (pinned on the CPU against the reference at N = 8000) and
+    the HIP kernels it switches to from 2e10 pairs on — on the same 60 000 x 50 000 problem, and on a whole two-scale loss."""
+    N, M = 60_000, 50_000
+    x, y = _uniform_clouds(31, N, M, cuda, shift=True)
+    gen = torch.Generator().manual_seed(2)
+    h = (torch.randn(M, generator=gen) * 2 - math.log(M)).to(cuda)
+    g, v = torch.randn(N, generator=gen).to(cuda), (torch.rand(M, generator=gen) / M).to(cuda)
+    eps = 0.05**2
+    res = {}
+    for use in (False, True):
+        monkeypatch.setattr(o64, "USE_HIP64", use)
+        monkeypatch.setattr(o64, "HIP64_MIN_PAIRS", 1.0)
+        a = np.full(20_000, 1.0 / 20_000)
+        res[use] = (o64.softmin(eps, x, y, h, device=cuda), o64.softmin_grad_x(eps, x, y, h, g, device=cuda),
+                    o64.softmin(0.05, x, y, h, p=1, device=cuda), o64.softmin_grad_x(0.05, x, y, h, g, p=1, device=cuda),
+                    o64.kconv("gaussian", x, y, v, 0.05, device=cuda), o64.kconv_grad_x("gaussian", x, y, v, g, 0.05, device=cuda),
+                    o64.kconv("energy", x, y, v, 0.05, device=cuda), o64.kconv_grad_x("laplacian", x, y, v, g, 0.05, device=cuda),
+                    o64.sinkhorn_multiscale(a, x[:20_000], a, y[:20_000], full=True, device=cuda, p=2, blur=0.05))
+    for k in range(8):
+        assert relerr(res[True][k], res[False][k]) < 1e-10, k
+    t, f = res[True][8], res[False][8]
+    assert abs(t["loss"] - f["loss"]) < 1e-11 * abs(f["loss"]) and relerr(t["gx"], f["gx"]) < 1e-9
+    assert np.abs(t["F"] - f["F"]).max() < 1e-11 and np.abs(t["G"] - f["G"]).max() < 1e-11
+    assert 0 < f["info"]["kept_fraction"][0] < 1
+
+
 # ---- configs[1]: online Sinkhorn, N = M = 1e5, 3D fp32 ----------------------------------------------------------------
 
 @pytest.mark.parametrize("shift", [False, True])

@@ -209,3 +209,26 @@ def test_torch64_fine_level_runs_of_clusters(monkeypatch, budget, p):
     assert abs(r - full["loss"]) <= 1e-11 * abs(r) and relerr(full["gx"], g) < 1e-10
     F, G = oracle_np.sinkhorn_multiscale(a, x, b, y, potentials=True, **kw)
     assert np.abs(F - full["F"]).max() < 1e-12 and np.abs(G - full["G"]).max() < 1e-12
+
+
+def test_hip64_pattern_covers_exactly_the_kept_blocks():
+    """``oracle_hip64.make_pattern`` (host side of the float64 HIP oracle: cluster keep mask -> per-row CSR lists of column
+    intervals) expands to the same point-level mask as ``oracle_np._expand_mask``, the construction the dense two-scale oracle
+    uses — including row clusters that keep nothing."""
+    from oracle import oracle_hip64
+    rng = np.random.default_rng(4)
+    N, M, ci, cj = 230, 190, 9, 7
+    cut = lambda n, c: np.r_[0, np.sort(rng.choice(np.arange(1, n), c - 1, replace=False)), n]      # noqa: E731
+    bi, bj = cut(N, ci), cut(M, cj)
+    ri, rj = np.stack([bi[:-1], bi[1:]], 1), np.stack([bj[:-1], bj[1:]], 1)
+    keep = rng.random((ci, cj)) < 0.4
+    keep[3, :] = False
+    lab, offsets, intervals = (t.numpy() for t in oracle_hip64.make_pattern(keep, ri, rj, "cpu"))
+    mask = np.zeros((N, M), bool)
+    for i in range(N):
+        for q in range(offsets[lab[i]], offsets[lab[i] + 1]):
+            assert not mask[i, intervals[q, 0]:intervals[q, 1]].any()      # intervals of a row are disjoint
+            mask[i, intervals[q, 0]:intervals[q, 1]] = True
+    assert np.array_equal(mask, oracle_np._expand_mask(keep, ri, rj, N, M))
+    empty = oracle_hip64.make_pattern(np.zeros((2, 2), bool), ri[:2], rj[:2], "cpu")
+    assert empty[1].tolist() == [0, 0, 0] and empty[2].shape == (1, 2)

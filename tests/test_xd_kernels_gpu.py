@@ -1,0 +1,207 @@
+"""Clouds of dimension 4 <= D <= 16 on the matrix cores (``csrc/glhip_softmin_xd.h``): soft-min forward, fused Sinkhorn half-step
+and gaussian kernel product, against the C oracle (``oracle/oracle_c.c``, float64) and — for launches the C oracle would take
+minutes on — sampled rows of the chunked float64 oracle (``oracle/oracle_torch64.py``).  The reference takes any D
+(``Vi({D})``, _legacy/sinkhorn_samples.py:322-334; its multiscale tutorial clusters 4-D clouds with user labels:
+examples/sinkhorn_multiscale/plot_optimal_transport_cluster.py:58-61,155-166).  Everything goes through the C-ABI.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from geomloss_amd import SamplesLoss, hip
+from geomloss_amd.cluster import from_matrix
+from oracle import oracle_c
+from oracle import oracle_torch64 as o64
+
+pytestmark = pytest.mark.gpu
+
+XD = [4, 5, 8, 9, 16]
+
+
+def _clouds(seed, N, M, D, B=None):
+    rng = np.random.default_rng(seed)
+    shp = (lambda n: (n, D)) if B is None else (lambda n: (B, n, D))
+    x = rng.random(shp(N)).astype(np.float32)
+    y = (rng.random(shp(M)) * 0.8 + 0.1).astype(np.float32)
+    h = rng.standard_normal(shp(M)[:-1]).astype(np.float32)
+    return x, y, h
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _tol(ref, D):
+    return 4e-7 * D + 2e-6 * np.abs(ref).max()       # expanded form in fp32: ~2^-22 diam^2 on a potential; diam^2 <= D here
+
+
+@pytest.mark.parametrize("D", XD)
+@pytest.mark.parametrize("N,M", [(300, 257), (1030, 2100), (64, 8), (1, 1), (5, 3000)])
+@pytest.mark.parametrize("eps", [1.0, 0.05**2])
+def test_softmin_fwd_vs_oracle(cuda, D, N, M, eps):
+    x, y, h = _clouds(N + M + D, N, M, D)
+    ref = oracle_c.softmin(eps, x, y, h, 2)
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):          # matrix cores with / without column splits; the VALU fallback
+        out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, flags=flags).cpu().numpy()
+        assert np.abs(out - ref).max() < _tol(ref, D), flags
+
+
+@pytest.mark.parametrize("D,N,M", [(4, 700, 70_001), (16, 300, 66_000), (4, 40_000, 15_000), (7, 33_000, 17_000), (12, 34_000, 16_000)])
+def test_softmin_fwd_large_launch_paths(cuda, D, N, M):
+    """M >= 65536: XCD-aware 1-D grid with 8-32 column splits.  N x M >= 5e8 pairs with >= 32768 rows: the 8-wavefront
+    workgroups (2 row tiles per wavefront up to D = 8).  100 sampled rows against the float64 oracle."""
+    x, y, h = _clouds(D + N, N, M, D)
+    eps = 0.07**2
+    rows = np.unique(np.r_[0, N - 1, np.random.default_rng(1).integers(0, N, 100)])
+    ref = o64.softmin(eps, x, y, h, rows=rows, device=cuda)
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda)).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out[rows] - ref).max() < _tol(ref, D)
+    alt = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=hip.FLAG_NO_SPLIT).cpu().numpy()
+    assert np.abs(out - alt).max() < 2 * _tol(ref, D)             # every row, against the unsplit launch
+
+
+def test_softmin_batched_bf16_and_fused_step(cuda):
+    B, N, M, D = 3, 257, 300, 6
+    x, y, logw = _clouds(3, N, M, D, B=B)
+    xb, yb = _t(x, cuda).bfloat16(), _t(y, cuda).bfloat16()
+    eps = 0.02
+    ref = np.stack([oracle_c.softmin(eps, xb[b].float().cpu().numpy(), yb[b].float().cpu().numpy(), logw[b], 2) for b in range(B)])
+    out = hip.softmin(eps, xb, yb, _t(logw, cuda)).cpu().numpy()
+    assert out.shape == (B, N) and np.abs(out - ref).max() < _tol(ref, D)
+    # glhip_sinkhorn_step == (prev + damping * softmin(eps, C, logw + pot / eps)) / 2
+    rng = np.random.default_rng(8)
+    pot = (rng.standard_normal(logw.shape) * 0.05).astype(np.float32)
+    prev = rng.standard_normal(x.shape[:-1]).astype(np.float32)
+    damping = 0.8
+    xt, yt = _t(x, cuda), _t(y, cuda)
+    unfused = 0.5 * (_t(prev, cuda) + damping * hip.softmin(eps, xt, yt, _t(logw + pot / np.float32(eps), cuda)))
+    fused = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), _t(pot, cuda), _t(prev, cuda), damping)
+    assert (fused - unfused).abs().max().item() < 2e-6
+    first = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping).cpu().numpy()
+    ref1 = damping * np.stack([oracle_c.softmin(eps, x[b], y[b], logw[b], 2) for b in range(B)])
+    assert np.abs(first - ref1).max() < _tol(ref1, D)
+    with pytest.raises(NotImplementedError):       # p = 1 has no fused kernel beyond D = 3, nothing has beyond D = 16
+        hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping, p=1)
+    with pytest.raises(NotImplementedError):
+        hip.sinkhorn_step(eps, torch.rand(10, 17, device=cuda), torch.rand(12, 17, device=cuda), torch.zeros(12, device=cuda),
+                          None, None, 0.5)
+
+
+@pytest.mark.parametrize("D", [4, 5, 16])
+def test_softmin_lazy_max_and_infinities(cuda, D):
+    """Late maxima, -inf / -1e5 dual values, exponents that climb faster than the speculative tile pass tolerates."""
+    N, M = 130, 2500
+    x, y, h = _clouds(9 + D, N, M, D)
+    h[:] = -50.0
+    h[-1] = 80.0
+    h[5] = -np.inf
+    h[6] = -100000.0
+    eps = 0.05**2
+    ref = oracle_c.softmin(eps, x, y, h, 2)
+    for flags in (0, hip.FLAG_NO_SPLIT):
+        out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=flags).cpu().numpy()
+        assert np.isfinite(out).all() and np.abs(out - ref).max() < _tol(ref, D)
+    h2 = (np.arange(M) // 64 * 48.0).astype(np.float32)
+    h2[M // 2:] -= 3000.0
+    h2[-3] = 5000.0
+    ref2 = oracle_c.softmin(eps, x, y, h2, 2)
+    out2 = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h2, cuda)).cpu().numpy()
+    assert np.isfinite(out2).all() and relerr(out2, ref2) < 2e-6
+    allinf = hip.softmin(eps, _t(x, cuda), _t(y, cuda), torch.full((M,), -math.inf, device=cuda)).cpu().numpy()
+    assert np.isposinf(allinf).all()                # soft-min over a measure without mass
+
+
+def _random_ranges(rng, N, M, ci, cj, density, dev):
+    cut_i = np.sort(rng.choice(np.arange(1, N), ci - 1, replace=False))
+    cut_j = np.sort(rng.choice(np.arange(1, M), cj - 1, replace=False))
+    ri = np.stack([np.r_[0, cut_i], np.r_[cut_i, N]], 1).astype(np.int32)
+    rj = np.stack([np.r_[0, cut_j], np.r_[cut_j, M]], 1).astype(np.int32)
+    keep = rng.random((ci, cj)) < density
+    keep[0, :] = False      # one row block with nothing to reduce over
+    keep[1, :] = True
+    rg = from_matrix(torch.from_numpy(ri).to(dev), torch.from_numpy(rj).to(dev), torch.from_numpy(keep).to(dev))
+    tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    return rg, tup, ri
+
+
+@pytest.mark.parametrize("D", [4, 9])
+def test_block_sparse_softmin_and_gaussian(cuda, D):
+    rng = np.random.default_rng(17)
+    N, M = 2300, 2600
+    x, y, h = _clouds(23, N, M, D)
+    rg, tup, ri = _random_ranges(rng, N, M, 9, 11, 0.4, cuda)
+    eps = 0.02
+    ref = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
+    empty = slice(ri[0, 0], ri[0, 1])
+    live = np.ones(N, bool)
+    live[empty] = False
+    for flags in (0, hip.FLAG_NO_SPLIT):
+        out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), ranges=rg, flags=flags).cpu().numpy()
+        assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()
+        assert np.abs(out[live] - ref[live]).max() < _tol(ref[live], D)
+    v = (np.abs(h) / M).astype(np.float32)
+    blur = 0.3
+    refk = oracle_c.kconv("gaussian", x, y, v, blur, ranges=tup)
+    k = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg).cpu().numpy()
+    assert (k[empty] == 0).all() and relerr(k, refk) < 1e-4
+
+
+@pytest.mark.parametrize("D", [4, 6, 11, 16])
+@pytest.mark.parametrize("N,M,B", [(300, 257, None), (1030, 2100, None), (150, 170, 3), (700, 70_001, None)])
+def test_gaussian_product_vs_oracle(cuda, D, N, M, B):
+    x, y, v = _clouds(77 + D, N, M, D, B=B)
+    v = np.abs(v) / M
+    v[..., ::7] *= -1.0                                    # signed weights are legal
+    blur = 0.25 * math.sqrt(D / 3)
+    one = lambda xa, ya, va: oracle_c.kconv("gaussian", xa, ya, va, blur)      # noqa: E731
+    ref = one(x, y, v) if B is None else np.stack([one(x[b], y[b], v[b]) for b in range(B)])
+    bound = one(x, y, np.abs(v)) if B is None else np.stack([one(x[b], y[b], np.abs(v[b])) for b in range(B)])
+    tol = 3e-6 * np.abs(ref).max() + 2.4e-7 * D / blur**2 * np.abs(bound).max()     # as in test_hip_kernels.py
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):
+        out = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=flags).cpu().numpy()
+        assert np.abs(out - ref).max() < tol, flags
+
+
+@pytest.mark.parametrize("name", ["sinkhorn_p2_d5", "gaussian_d6"])
+def test_reference_goldens_in_higher_dimension(cuda, name):
+    """The two reference-generated golden cases with D > 3 (tests/golden/make_golden.py), through SamplesLoss(backend="online"):
+    loss <= 1e-4 of the reference's float64 value, with the forward reductions on the matrix cores."""
+    rec = load_golden(name)
+    x, y = _t(rec["x"].astype(np.float32), cuda), _t(rec["y"].astype(np.float32), cuda)
+    a, b = _t(rec["a"].astype(np.float32), cuda), _t(rec["b"].astype(np.float32), cuda)
+    assert x.shape[-1] > 3
+    xg = x.clone().requires_grad_(True)
+    L = SamplesLoss(backend="online", **rec["kwargs"])(a, xg, b, y)
+    (gx,) = torch.autograd.grad(L, [xg])
+    assert abs(L.item() - float(rec["loss_f64"])) <= 1e-4 * abs(float(rec["loss_f64"]))
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < 1e-4
+
+
+def test_multiscale_4d_with_user_labels(cuda):
+    """The reference's recipe for D > 3 (plot_optimal_transport_cluster.py:155-166): clusters given as labels — here voxels of
+    the three spatial coordinates of (position, feature) points — and the two-scale solver on the 4-D clouds.  Against the online
+    backend on the same clouds (the truncation error of a two-scale run at truncate = 5 is ~1e-3 of the loss) and, for the
+    block-sparse reductions it runs, see test_block_sparse_softmin_and_gaussian."""
+    g = torch.Generator().manual_seed(7)
+    N, M = 6000, 7000
+    x = torch.rand(N, 4, generator=g).to(cuda)
+    y = (torch.rand(M, 4, generator=g) * torch.tensor([0.7, 0.7, 0.7, 1.0]) + torch.tensor([0.2, 0.2, 0.2, 0.0])).to(cuda)
+    def lab(t):       # compact labels 0..C-1 in voxel order, as pykeops' grid_cluster would give for the spatial coordinates
+        code = ((t[:, :3] / 0.2).floor().long() * torch.tensor([36, 6, 1], device=cuda)).sum(1)
+        return torch.unique(code, return_inverse=True)[1].int()
+
+    kw = dict(p=2, blur=0.05, scaling=0.7)
+    xg = x.clone().requires_grad_(True)
+    a, b = torch.full((N,), 1.0 / N, device=cuda), torch.full((M,), 1.0 / M, device=cuda)
+    Lm = SamplesLoss("sinkhorn", backend="multiscale", **kw)(lab(x), a, xg, lab(y), b, y)
+    (gm,) = torch.autograd.grad(Lm, [xg])
+    xo = x.clone().requires_grad_(True)
+    Lo = SamplesLoss("sinkhorn", backend="online", **kw)(xo, y)
+    (go,) = torch.autograd.grad(Lo, [xo])
+    assert abs(Lm.item() - Lo.item()) < 5e-3 * abs(Lo.item())
+    assert torch.isfinite(gm).all() and (gm - go).abs().max() < 0.05 * go.abs().max()
