@@ -21,7 +21,15 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
                 nf = nf > nx ? nf : nx;
             }
         }
+        // forward partials: 2 floats per row and split; gradient kernels (glhip_wsum_t32.h, 256-row blocks): D + 1
         size_t bytes = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float);
+        int ng = choose_splits(n_ranges > 0 ? n_ranges : (long)B * ((N + 255) / 256), M, n_ranges, 1L << 30);
+        if (n_ranges == 0 && M >= 65536) {
+            const int nx = xcd_splits((long)B * ((N + 255) / 256), M, kXdSlots, 32);
+            ng = ng > nx ? ng : nx;
+        }
+        const size_t grad = (size_t)(ng < 2 ? 0 : ng) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
+        bytes = bytes > grad ? bytes : grad;
         if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);
         return bytes;
     }

@@ -28,8 +28,8 @@ int glhip_softmin_fwd_grad(const void* x, const void* y, const float* h, const f
                            size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_softmin_fwd_grad", x, y, h, B, N, M, D, in_dtype, ranges_i, slices_i, redranges_j, n_ranges);
     if (rc) return rc;
-    if (p != 2 || D > 3 || (flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT)))
-        return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd_grad: only p = 2, D <= 3 on the matrix-core kernels (got p %d, D %d, flags %d): "
+    if (p != 2 || D > kXdMaxD || (flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT)))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd_grad: only p = 2, D <= 16 on the matrix-core kernels (got p %d, D %d, flags %d): "
                                         "call glhip_softmin_fwd + glhip_softmin_bwd_x", p, D, flags);
     if (B == 0 || N == 0) return GLHIP_OK;
     if (!guess || !out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_softmin_fwd_grad: NULL guess / out / grad_unit");

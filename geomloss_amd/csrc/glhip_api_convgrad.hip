@@ -30,9 +30,9 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
     if (rc) return rc;
     if (kind < GLHIP_GAUSSIAN || kind > GLHIP_ENERGY)
         return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: unknown kernel id %d", kind);
-    if (D > 3)
-        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: D <= 3 only (got D %d): call glhip_kernel_conv_fwd + "
-                                        "glhip_kernel_conv_bwd_x", D);
+    if (D > 3 && !(kind == GLHIP_GAUSSIAN && D <= kXdMaxD && !(flags & GLHIP_FLAG_NO_MFMA)))
+        return fail(GLHIP_EUNSUPPORTED, "glhip_kernel_conv_fwd_grad: D <= 3 (gaussian on the matrix cores: D <= 16) only (got kind %d, "
+                                        "D %d, flags %d): call glhip_kernel_conv_fwd + glhip_kernel_conv_bwd_x", kind, D, flags);
     if (B == 0 || N == 0) return GLHIP_OK;
     if (!out || !grad_unit) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: NULL out / grad_unit");
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
@@ -48,6 +48,15 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
             prm.gscale = -1.0f / (prm.t * blur * blur);
             prm.clamp2 = 0.f;
             if (flags & GLHIP_FLAG_NO_MFMA) launch_conv_d<GLHIP_GAUSSIAN, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+            else if (D > 3) {         // 4 <= D <= 16: transposed 32x32x16 kernel (glhip_wsum_t32.h)
+#define GL_XD(DD) launch_gauss_grad_t32<DD, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+            } else if (flags & GLHIP_FLAG_T32) {
+                if (D == 1) launch_gauss_grad_t32<1, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                else if (D == 2) launch_gauss_grad_t32<2, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                else launch_gauss_grad_t32<3, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+            }
             else if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
             else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
             else launch_gauss_fwdgrad<3, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);

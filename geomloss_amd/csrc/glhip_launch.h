@@ -18,6 +18,7 @@
 #include "glhip_wsum_x32.h"
 #include "glhip_dist_x32.h"
 #include "glhip_softmin_xd.h"
+#include "glhip_wsum_t32.h"
 
 using namespace glhip;
 
@@ -378,6 +379,70 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
     else launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
 
+// weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
+template <int MODE, int D, typename T, class MergeOp>
+void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
+                     int M, const Scratch& sc, hipStream_t st) {
+    constexpr int kPart = (MODE == WS_GAUSS_BWD) ? D : D + 1;
+    static_assert(MergeOp::kPartial == kPart, "partial formats differ");
+    static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and main kernel must tile rows alike");
+    constexpr int RT = (D <= 8) ? 2 : 1, NW = 8 / RT;       // 256 rows per workgroup either way; 2 row tiles share the LDS reads
+    unsigned chunk_grid = 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kMfmaRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
+    const long per_split = (long)B * N * kPart * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * kPart;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    const int gx = (N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock;
+    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
+        const int nx = xcd_splits((long)gx * B, M, kXdSlots, fit);
+        const long total = (long)gx * B * nx;
+        if (total < (1L << 31)) {
+            sp.n_splits = nx;
+            sp.xcd_grid_x = gx;
+            sp.xcd_blocks = gx * B;
+            hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+            return;
+        }
+    }
+    if (n_ranges > 0) {
+        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, true, RT, NW>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+    } else {
+        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+    }
+}
+
+// soft-min gradient (and value + gradient) through the transposed kernel
+template <int D, typename T>
+void launch_softmin_bwd_t32(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
+                            hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.h; w.fwd = prm.fwd; w.g = prm.g; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = prm.s2; w.out_scale = prm.out_scale; w.gscale = 1.f; w.tscale = prm.shift2;
+    launch_wsum_t32<WS_SOFTMIN_BWD, D, T, SoftminBwdOp<D, 2, false, 1, T>>(w, prm, rg, n_ranges, B, N, M, sc, st);
+}
+
+// gaussian gradient (FWDGRAD = false) or product + unit gradient (true) through the transposed kernel
+template <int D, bool FWDGRAD, typename T>
+void launch_gauss_grad_t32(const ConvParams<T>& prm, float blur, const Ranges& rg, int n_ranges, int B, int N, int M, const Scratch& sc,
+                           hipStream_t st) {
+    WsumParams<T> w;
+    w.x = prm.x; w.y = prm.y; w.s = prm.v; w.fwd = nullptr; w.g = prm.g; w.out = prm.out; w.gx = prm.gx;
+    w.s2 = kLog2e / (blur * blur); w.out_scale = 1.f; w.gscale = -1.0f / (blur * blur); w.tscale = prm.t;
+    if constexpr (FWDGRAD) launch_wsum_t32<WS_GAUSS_FWDGRAD, D, T, GaussFwdGradMerge<D, T>>(w, prm, rg, n_ranges, B, N, M, sc, st);
+    else launch_wsum_t32<WS_GAUSS_BWD, D, T, ConvOp<GLHIP_GAUSSIAN, D, 1, T, 1>>(w, prm, rg, n_ranges, B, N, M, sc, st);
+}
+
 #define GLHIP_XD_DISPATCH(D, CALL)                                                                                        \
     switch (D) {                                                                                                          \
         case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;              \
@@ -528,6 +593,14 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
                 return GLHIP_OK;
             }
         }
+        if constexpr (BWD) {
+            if (p == 2 && mfma && !direct && (flags & GLHIP_FLAG_T32)) {      // transposed 32x32x16 gradient kernel (glhip_wsum_t32.h)
+                if (D == 1) launch_softmin_bwd_t32<1, T>(prm, rg, n_ranges, B, N, M, sc, st);
+                else if (D == 2) launch_softmin_bwd_t32<2, T>(prm, rg, n_ranges, B, N, M, sc, st);
+                else launch_softmin_bwd_t32<3, T>(prm, rg, n_ranges, B, N, M, sc, st);
+                return GLHIP_OK;
+            }
+        }
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
@@ -536,6 +609,15 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
             if (p == 2 && D <= kXdMaxD && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // 4 <= D <= 16: matrix cores
                 SoftminParams<T> prm = make_softmin_params<T>(x, y, h, out, eps, 2, step.pot, step.prev, step.alpha, step.beta);
 #define GL_XD(DD) launch_xd<XD_SOFTMIN, DD, T, SoftminFwdOp<DD, 2, false, 1, T>>(prm, prm, rg, n_ranges, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
+        } else {
+            if (p == 2 && D <= kXdMaxD && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // gradient (+ value), 4 <= D <= 16
+                SoftminParams<T> prm = make_softmin_params<T>(x, y, h, out, eps, 2, nullptr, nullptr, 1.f, 0.f);
+                prm.fwd = fwd; prm.g = g; prm.gx = gx; prm.shift2 = step.shift2;
+#define GL_XD(DD) launch_softmin_bwd_t32<DD, T>(prm, rg, n_ranges, B, N, M, sc, st)
                 GLHIP_XD_DISPATCH(D, GL_XD)
 #undef GL_XD
                 return GLHIP_OK;
@@ -625,6 +707,14 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.t = std::sqrt(0.5f * kLog2e) / blur;
             prm.gscale = -1.0f / (prm.t * blur * blur);
             prm.clamp2 = 0.f;
+            if constexpr (BWD) {
+                if ((flags & GLHIP_FLAG_NO_MFMA) == 0 && (flags & GLHIP_FLAG_T32)) {
+                    if (D == 1) launch_gauss_grad_t32<1, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                    else if (D == 2) launch_gauss_grad_t32<2, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                    else launch_gauss_grad_t32<3, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
+                    return GLHIP_OK;
+                }
+            }
             if ((flags & GLHIP_FLAG_NO_MFMA) == 0) {
                 const bool x32 = (flags & GLHIP_FLAG_XDL16) == 0;
                 if (D == 1) launch_gauss_mfma<1, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);
@@ -679,6 +769,18 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
                 mprm.x = prm.x; mprm.y = prm.y; mprm.v = v; mprm.out = out; mprm.g = nullptr; mprm.gx = nullptr;
                 mprm.t = 1.f; mprm.gscale = 0.f; mprm.clamp2 = 0.f;
 #define GL_XD(DD) launch_xd<XD_GAUSS, DD, T, ConvOp<GLHIP_GAUSSIAN, DD, 1, T, 0>>(prm, mprm, rg, n_ranges, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
+        } else {
+            if (kind == GLHIP_GAUSSIAN && D <= kXdMaxD && !(flags & GLHIP_FLAG_NO_MFMA)) {   // gaussian gradient, 4 <= D <= 16
+                ConvParams<T> prm;
+                prm.x = static_cast<const T*>(x); prm.y = static_cast<const T*>(y); prm.v = v; prm.out = out; prm.g = g; prm.gx = gx;
+                prm.t = std::sqrt(0.5f * kLog2e) / blur;
+                prm.gscale = -1.0f / (prm.t * blur * blur);
+                prm.clamp2 = 0.f;
+#define GL_XD(DD) launch_gauss_grad_t32<DD, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st)
                 GLHIP_XD_DISPATCH(D, GL_XD)
 #undef GL_XD
                 return GLHIP_OK;

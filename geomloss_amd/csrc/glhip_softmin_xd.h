@@ -103,7 +103,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
     __shared__ uint4 tile[kTileD * NBP];                      // [column group of 32][K block 0..NBP-1][column]
-    __shared__ float tileV[MODE == XD_GAUSS ? kTileD : 4];    // gaussian: the weights v_j of the tile
+    __shared__ __attribute__((aligned(16))) float tileV[MODE == XD_GAUSS ? kTileD : 4];    // gaussian: the weights v_j of the tile (read back as float4)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

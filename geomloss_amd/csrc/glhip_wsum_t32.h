@@ -1,0 +1,237 @@
+// glhip_wsum_t32.h — the weighted-sum reductions (soft-min gradient, gaussian gradient, gaussian product + gradient) on TRANSPOSED
+// 32 x 32 matrix-core blocks, for 1 <= D <= 16.
+//
+//     R_i[c] = sum_j  2^( [a_i,1].[yt_j,H_j] + C_i ) * q_j[c]          (modes and the meaning of C_i, q_j: WsumMode, glhip_wsum_mfma.h)
+//
+// glhip_wsum_mfma.h (16x16x32 MFMAs) and the rejected 32x32 variant of glhip_wsum_x32.h keep the MFMA rows = rows x_i: a lane
+// then holds 4 (16) different ROWS, each with its own D + 1 accumulators — 64 accumulator registers at D = 3, out of reach beyond.
+// Here the block is transposed exactly as in the forward kernels (glhip_softmin_x32.h / _xd.h): the MFMA "A" rows are 32 columns
+// y_j from LDS, the "B" columns are 32 rows x_i in registers, so lane l owns ONE row (l % 32) and its 16 result registers are 16
+// columns.  The accumulators are D + 1 (soft-min: D + mass) registers per row tile whatever D is, the per-row constant C_i rides
+// in the spare K slots of the scalar block, and what the transposition costs is that the small per-column vectors q_j are no
+// longer "one register per lane": they are read from LDS, component by component, as broadcast float4 (4 consecutive columns of
+// the lane's half: register k <-> column (k / 4) * 8 + 4 * half + k % 4) — 4 (D + 1) ds_read_b128 per 32-column group, shared by the
+// RT row tiles of the wavefront.  Per 1024 pairs and row tile: NM MFMAs, 16 v_exp_f32, 16 (D + 1) v_fma_f32 / v_add_f32.
+//
+// Used for 4 <= D <= 16 (before: the one-thread-per-row VALU kernel of glhip_generic.h) and, behind GLHIP_FLAG_T32, for D <= 3.
+#pragma once
+
+#include "glhip_softmin_xd.h"
+#include "glhip_wsum_mfma.h"
+
+namespace glhip {
+
+template <int D>
+struct T32Shape {      // XdShape without its D >= 4 restriction
+    static constexpr int NB = D + 1;
+    static constexpr int NM = (NB + 1) / 2;
+    static constexpr int NBP = 2 * NM;
+    static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);
+    static constexpr int HM = D / 2, HH = D % 2;
+};
+
+template <int MODE, int D>
+struct T32Q {           // components of q_j kept in LDS, accumulators per row
+    static constexpr int NQ = (MODE == WS_SOFTMIN_BWD) ? D : D + 1;     // soft-min: yt_j (the mass needs no q);  gaussian: (v yt_j, v)
+    static constexpr int NA = D + 1;
+};
+
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    using S = T32Shape<D>;
+    constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
+    constexpr int NQ = T32Q<MODE, D>::NQ, NA = T32Q<MODE, D>::NA;
+    constexpr int kRowsPerWave = RT * 32;
+    constexpr int kRowsPerBlock = NW * kRowsPerWave;
+    constexpr int kThreads = NW * 64;
+    static_assert(kRowsPerBlock == kMfmaRowsPerBlock, "the merge kernels tile rows (and centre their partials) in blocks of 256");
+    static_assert(MODE == WS_SOFTMIN_BWD || MODE == WS_GAUSS_BWD || MODE == WS_GAUSS_FWDGRAD, "product-only mode: glhip_softmin_xd.h");
+    __shared__ uint4 tile[kTileD * NBP];          // [column group of 32][K block][column]
+    __shared__ __attribute__((aligned(16))) float tileQ[NQ * kTileD];          // [component][column]: read back as float4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
+    const int ns = sp.n_splits;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int rec0 = half * 32 + l31;
+
+    int row_begin, row_end, q_begin, q_end;
+    block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint4 kZero = uint4{0u, 0u, 0u, 0u};
+
+    for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
+        float centre[D];
+        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+
+        const int wave_row0 = row0 + wave * kRowsPerWave;
+        const bool wave_active = wave_row0 < row_end;
+        uint4 X[RT][NM];
+        float acc[RT][NA];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int i = min(wave_row0 + rt * 32 + l31, row_end - 1);
+            float xi[D];
+            load_point<D, T>(prm.x, (long)b * N + i, xi);
+            float a[D], n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float xt = xi[d] - centre[d];
+                n2 = __builtin_fmaf(xt, xt, n2);
+                a[d] = xt * prm.s2;
+            }
+            // per-row constant of the exponent: r_i = -s/2 |xt_i|^2, minus (LSE2_i - r_i)'s other half for the soft-min gradient:
+            //   C_i = r_i - LSE2_i, LSE2_i = fwd_i / out_scale (+ tscale: value-and-gradient mode, `fwd` is a guess and tscale the margin)
+            float cst = -0.5f * prm.s2 * n2;
+            if (MODE == WS_SOFTMIN_BWD) cst -= prm.fwd[(long)b * N + i] / prm.out_scale + prm.tscale;
+            const uint4 hblk = pack_negmax(-cst);      // [1,1,1,c1,c2,c3,0,0]
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) {
+                const int kb0 = 2 * mm, kb1 = 2 * mm + 1;
+                const float av = (kb1 < D) ? (half ? a[kb1 < D ? kb1 : 0] : a[kb0]) : a[kb0 < D ? kb0 : 0];
+                uint4 pa = pack_a(av);
+                if (kb0 == D) pa = hblk;
+                if (kb1 == D) pa = select_u4(half != 0, hblk, pa);
+                if (kb1 > D) pa = select_u4(half != 0, kZero, pa);
+                X[rt][mm] = pa;
+            }
+#pragma unroll
+            for (int c = 0; c < NA; ++c) acc[rt][c] = 0.f;
+        }
+
+        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
+            int js, je;
+            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            for (int j0 = js; j0 < je; j0 += kTileD) {
+                const int n = min(kTileD, je - j0);
+                const int npad = (n + 31) & ~31;
+                __syncthreads();
+                for (int t = tid; t < npad; t += kThreads) {
+                    float yt[D], H = kNegBig, sj = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) yt[d] = 0.f;
+                    if (t < n) {
+                        const long col = (long)b * M + j0 + t;
+                        float yj[D];
+                        load_point<D, T>(prm.y, col, yj);
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            yt[d] = yj[d] - centre[d];
+                            n2 = __builtin_fmaf(yt[d], yt[d], n2);
+                        }
+                        sj = prm.s[col];
+                        H = (MODE == WS_SOFTMIN_BWD) ? __builtin_fmaf(-0.5f * prm.s2, n2, sj * kLog2e) : -0.5f * prm.s2 * n2;
+                    }
+                    uint4* base = &tile[(t >> 5) * (32 * NBP) + (t & 31)];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) base[d * 32] = pack_y(yt[d]);
+                    base[D * 32] = pack_h1(H);
+                    if (NBP > S::NB) base[S::NB * 32] = kZero;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) tileQ[d * kTileD + t] = (MODE == WS_SOFTMIN_BWD) ? yt[d] : sj * yt[d];
+                    if (MODE != WS_SOFTMIN_BWD) tileQ[D * kTileD + t] = (t < n) ? sj : 0.f;
+                }
+                __syncthreads();
+                if (!wave_active) continue;
+
+                for (int G = 0; G < npad / 32; ++G) {
+                    const uint4* g = &tile[G * (32 * NBP)];
+                    f32x16 w[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x16 u = xd_block<NM, NBP>(g, rec0, X[rt], zero16);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) w[rt][k] = fast_exp2(u[k]);
+                    }
+                    const float* qg = &tileQ[G * 32 + half * 4];
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const float4 q4 = *reinterpret_cast<const float4*>(qg + c * kTileD + qq * 8);
+                            const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[rt][c] = __builtin_fmaf(w[rt][qq * 4 + r], qv[r], acc[rt][c]);
+                            }
+                        }
+                    }
+                    if (MODE == WS_SOFTMIN_BWD) {      // the plan mass: sum of the weights themselves
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s4[k & 3] += w[rt][k];
+                            acc[rt][D] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (wave_active) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float a_[NA];
+#pragma unroll
+                for (int c = 0; c < NA; ++c) a_[c] = acc[rt][c] + __shfl_xor(acc[rt][c], 32, 64);   // the two 16-column halves
+                const int i = wave_row0 + rt * 32 + l31;
+                if (half == 0 && i < row_end) {
+                    const long idx = (long)b * N + i;
+                    float xt[D];
+                    {
+                        float xi[D];
+                        load_point<D, T>(prm.x, idx, xi);
+#pragma unroll
+                        for (int d = 0; d < D; ++d) xt[d] = xi[d] - centre[d];
+                    }
+                    float* part = sp.workspace + split * sp.split_stride + idx * (D + 1 - (MODE == WS_GAUSS_BWD ? 1 : 0));
+                    if (MODE == WS_SOFTMIN_BWD) {
+                        // a_[d] = sum_j P_ij yt_jd, a_[D] = sum_j P_ij;  d f_i / d x_i = x_i - sum_j P_ij y_j / sum_j P_ij
+                        if (ns == 1) {
+                            const float gi = prm.g ? prm.g[idx] : 1.f;
+                            const float inv = (a_[D] > 0.f) ? 1.0f / a_[D] : 0.f;
+#pragma unroll
+                            for (int d = 0; d < D; ++d) prm.gx[idx * D + d] = gi * (xt[d] - a_[d] * inv);
+                            if (prm.out)   // value-and-gradient mode: the mass turns the guess into the exact soft-min
+                                prm.out[idx] = prm.fwd[idx] + prm.out_scale * (prm.tscale + fast_log2(a_[D]));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < NA; ++c) part[c] = a_[c];      // SoftminBwdOp::merge_row: relative to x[row0], as here
+                        }
+                    } else if (MODE == WS_GAUSS_FWDGRAD) {
+                        // a_[d] = sum_j v_j k_ij yt_jd, a_[D] = sum_j v_j k_ij = the product;  d out_i / d x_i = gscale (xt S0 - S1)
+                        if (ns == 1) {
+                            prm.out[idx] = a_[D];
+#pragma unroll
+                            for (int d = 0; d < D; ++d) prm.gx[idx * D + d] = prm.gscale * (xt[d] * a_[D] - a_[d]);
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < D; ++d) part[d] = prm.tscale * (xt[d] * a_[D] - a_[d]);
+                            part[D] = a_[D];
+                        }
+                    } else {
+                        if (ns == 1) {
+                            const float gi = prm.g[idx] * prm.gscale;
+#pragma unroll
+                            for (int d = 0; d < D; ++d) prm.gx[idx * D + d] = gi * (xt[d] * a_[D] - a_[d]);
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < D; ++d) part[d] = prm.tscale * (xt[d] * a_[D] - a_[d]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace glhip

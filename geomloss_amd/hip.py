@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
 GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
-FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST = 1, 2, 4, 8, 16, 32, 64
+FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST, FLAG_T32 = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
 XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussian product run on the matrix cores up to this dimension
 
@@ -251,7 +251,7 @@ def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
 
 def softmin_fwd_grad_raw(x, y, h, guess, margin, eps, ranges=None, flags=0):
     """Soft-min and d out_i / d x_i in one reduction, given a guess within ``margin`` of the answer (``glhip_softmin_fwd_grad``;
-    p = 2, D <= 3) -> (B,N), (B,N,D)."""
+    p = 2, D <= 16) -> (B,N), (B,N,D)."""
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
@@ -542,9 +542,9 @@ _VALUE_GRAD_MAX_MARGIN = 25.0       # in units of eps: the weights stay >= exp(-
 
 def softmin_value_and_grad(eps, x, y, h, guess, margin, ranges=None, flags=0):
     """``softmin(eps, x, y, h)`` (differentiable in x) from one reduction instead of a forward and a backward one, or None when that
-    does not apply: x needs no gradient, p = 2 / D <= 3 kernels only, launches too small to pay for the host check of ``margin``
+    does not apply: x needs no gradient, p = 2 / D <= 16 kernels only, launches too small to pay for the host check of ``margin``
     (a device scalar: sup |h - h_previous| * eps), or a margin beyond 25 eps (the loop has not converged: use the two passes)."""
-    if not (torch.is_grad_enabled() and x.requires_grad) or x.shape[-1] > 3 or (int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT):
+    if not (torch.is_grad_enabled() and x.requires_grad) or x.shape[-1] > XD_MAX_DIM or (int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT):
         return None
     rows, cols = x.shape[-2], y.shape[-2]
     B = 1 if x.dim() == 2 else x.shape[0]
@@ -728,7 +728,9 @@ class _KernelConv(torch.autograd.Function):
             yb = yb.to(xb.dtype)
         # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
         # carries one more accumulator, the product itself.  The backward pass is then elementwise.
-        fused = _fuse_kernel_grad and xb.shape[-1] <= 3 and ctx.needs_input_grad[1]
+        # (D <= 3: every kernel; 4 <= D <= 16: the gaussian kernel on the matrix cores)
+        fused = (_fuse_kernel_grad and ctx.needs_input_grad[1]
+                 and (xb.shape[-1] <= 3 or (kind == GAUSSIAN and xb.shape[-1] <= XD_MAX_DIM and not (flags & FLAG_NO_MFMA))))
         plan = None if fused or kind == GAUSSIAN or (flags & FLAG_GRAD_FAMILY) else compact_rows_plan(xb, yb, ranges, flags)
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
