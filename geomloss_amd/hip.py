@@ -391,6 +391,7 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
 # spatially compact — the condition under which the squared distance may come from the MFMA (glhip_dist_x32.h)
 _dist_on_mfma = os.environ.get("GEOMLOSS_HIP_MFMA_DIST", "1") != "0"
 _DIST_MIN_ROWS, _DIST_MIN_PAIRS, _DIST_ROWS_PER_VOXEL, _DIST_COL_CHUNKS = 65536, 5e8, 256, 8
+_DIST_SLAB = 256          # rows per row block of a compact-rows plan = the row tile of the distance kernel (8 wavefronts x 32 rows)
 
 
 def set_distance_on_mfma(enabled):
@@ -411,27 +412,55 @@ def _voxel_for(x, rows_per_voxel):
     return max((vol * rows_per_voxel / N) ** (1.0 / max(len(live), 1)), max(ext) / (1 << 20), 1e-30)
 
 
+def _serpentine(perm, xs, ranges, cents, voxel):
+    """Re-orders the voxel clusters of a lexicographically voxel-sorted cloud along a boustrophedon path (the scan direction of
+    every axis flips each time the path index of the axes before it advances), so that voxels that follow each other in memory
+    are always face neighbours in space.  ANY run of consecutive rows of the result is then spatially compact — which is what
+    lets :class:`_CompactRows` cut the rows into equal slabs instead of one (unevenly filled) block per voxel.
+    perm (N,) int64, xs (N,D) sorted cloud, ranges (C,2), cents (C,D) -> (perm, xs) in the new order."""
+    q = torch.floor(cents.float() / voxel).long()
+    q = q - q.amin(0)
+    ext = q.amax(0) + 1
+    path = torch.zeros_like(q[:, 0])
+    for a in range(q.shape[1]):
+        c = torch.where(path % 2 == 1, ext[a] - 1 - q[:, a], q[:, a])
+        path = path * ext[a] + c
+    order = torch.argsort(path)
+    sizes = (ranges[:, 1] - ranges[:, 0]).long()[order]
+    starts = ranges[:, 0].long()[order]
+    offs = torch.cumsum(sizes, 0) - sizes                                   # first row of every cluster in the new order
+    idx = torch.repeat_interleave(starts - offs, sizes) + torch.arange(xs.shape[0], device=xs.device)
+    return perm[idx], xs[idx]
+
+
 class _CompactRows:
-    """Voxel-sorted copies of the two clouds of a dense launch + the block-sparse pattern "every row block x all columns" (in a
-    few column chunks, so that the column splits of the launch have something to split).  Rows: one voxel = one row block, the
-    condition for the matrix-core distances.  Columns: sorted too, so that the tiles a workgroup streams are spatially coherent
-    and only the few tiles that overlap its own voxel run the near-pair test."""
+    """Spatially sorted copies of the two clouds of a dense launch + the block-sparse pattern "every slab of 256 rows x all
+    columns" (in a few column chunks, so that the column splits of the launch have something to split).  Both clouds are sorted
+    by voxel (``glhip_grid_cluster``) and the voxels chained along a boustrophedon path, so that every run of consecutive rows —
+    a 256-row slab, a 512-column tile — is spatially compact: the condition for the matrix-core distances (rows), and what lets
+    all but the few tiles around a slab skip the near-pair test (columns).  Slabs rather than one row block per voxel: voxels hold
+    244 +- 31 points where 256 were aimed at, and a workgroup per voxel left 18 % of the lanes idle (energy product at 1e6:
+    125 -> 105 ms; profiles/r03_dist_blocks.txt)."""
 
     def __init__(self, xb, yb):
         x, y = xb[0], yb[0]
-        M = y.shape[0]
-        self.perm, xs, _, ranges, _, _ = grid_cluster_raw(x.contiguous(), None, _voxel_for(x, _DIST_ROWS_PER_VOXEL))
-        self.perm_y, ys, _, _, _, _ = grid_cluster_raw(y.contiguous(), None, _voxel_for(y, 2 * _DIST_ROWS_PER_VOXEL))
-        self.perm, self.perm_y = self.perm.long(), self.perm_y.long()
-        self.x, self.y = xs.unsqueeze(0), ys.unsqueeze(0)
-        C = ranges.shape[0]
+        N, M = x.shape[0], y.shape[0]
+        vx, vy = _voxel_for(x, _DIST_ROWS_PER_VOXEL), _voxel_for(y, 2 * _DIST_ROWS_PER_VOXEL)
+        perm, xs, _, ranges, cents, _ = grid_cluster_raw(x.contiguous(), None, vx)
+        self.perm, xs = _serpentine(perm.long(), xs, ranges, cents, vx)
+        perm_y, ys, _, ranges_y, cents_y, _ = grid_cluster_raw(y.contiguous(), None, vy)
+        self.perm_y, ys = _serpentine(perm_y.long(), ys, ranges_y, cents_y, vy)
+        self.x, self.y = xs.unsqueeze(0).contiguous(), ys.unsqueeze(0).contiguous()
+        C = (N + _DIST_SLAB - 1) // _DIST_SLAB
+        first = torch.arange(C, device=x.device, dtype=torch.int32) * _DIST_SLAB
+        ranges = torch.stack((first, (first + _DIST_SLAB).clamp_max(N)), 1).contiguous()
         nchunk = _DIST_COL_CHUNKS
         step = ((M + nchunk - 1) // nchunk + 31) // 32 * 32
         starts = torch.arange(nchunk, device=x.device, dtype=torch.int32) * step
         cols = torch.stack((starts.clamp_max(M), (starts + step).clamp_max(M)), 1)      # (nchunk, 2)
         red = cols.repeat(C, 1).contiguous()
         slices = (torch.arange(1, C + 1, device=x.device, dtype=torch.int32) * nchunk).contiguous()
-        self.ranges = BlockRanges(ranges.contiguous(), slices, red, None, None, None)
+        self.ranges = BlockRanges(ranges, slices, red, None, None, None)
 
     def cols(self, t):
         """A (1, M) per-column vector in the sorted column order."""

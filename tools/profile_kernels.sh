@@ -2,24 +2,26 @@
 # GPU box: kernel-trace stats + PMC passes (one counter group per pass, no other trace domain) over tools/kernels_1e6.py.
 # Output: gpurun_out/prof_kernels_<tag>/summary.txt ; copy into profiles/.
 set -u
-TAG=${1:-r02}; REPO=$(pwd); OUT=$REPO/gpurun_out/prof_kernels_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-CMD="python $REPO/tools/kernels_1e6.py"
+# usage: tools/profile_kernels.sh <tag> [script under tools/, default kernels_1e6.py]
+TAG=${1:-r03}; SCRIPT=${2:-kernels_1e6.py}; REPO=$(pwd); OUT=$REPO/gpurun_out/prof_kernels_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+CMD="python $REPO/tools/$SCRIPT"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace -d $OUT/pmc_util -o pmc -- $CMD > $OUT/pmc_util.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_inst -o pmc -- $CMD > $OUT/pmc_inst.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_wait -o pmc -- $CMD > $OUT/pmc_wait.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 cd $REPO
 python - <<PY > $OUT/summary.txt
 import sqlite3, glob, collections
-print("# rocprofv3 over tools/kernels_1e6.py (N = M = 1e6, D = 3, fp32; 2 launches of each reduction); MI355X")
+print("# rocprofv3 over tools/$SCRIPT (N = M = 1e6, D = 3, fp32; 2 launches of each reduction); MI355X")
 for db in glob.glob("$OUT/trace/**/*.db", recursive=True):
     c = sqlite3.connect(db)
     print("## --kernel-trace --stats (top_kernels): calls, average us, % of GPU time")
-    for r in list(c.execute("select name, total_calls, average, percentage from top_kernels"))[:12]:
+    for r in list(c.execute("select name, total_calls, average, percentage from top_kernels"))[:16]:
         print(f"{r[1]:5d}  {r[2]:12.1f}  {r[3]:6.2f}%  {r[0][:140]}")
 vals = collections.defaultdict(dict)
-for sub in ("pmc_util", "pmc_inst", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_util", "pmc_inst", "pmc_wait", "pmc_fetch", "pmc_write"):
     for db in glob.glob("$OUT/" + sub + "/**/*.db", recursive=True):
         c = sqlite3.connect(db)
         for k, cn, n, avg, dur in c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"):
