@@ -64,12 +64,14 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
             prm.t = kLog2e / blur;
             prm.gscale = -1.0f / blur;
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;
-            launch_conv_d<GLHIP_LAPLACIAN, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+            if (use_mfma_dist(flags, n_ranges, B, D)) launch_dist_grad_d<GLHIP_LAPLACIAN, DG_FWDGRAD, T>(prm, rg, n_ranges, N, M, D, sc, st);
+            else launch_conv_d<GLHIP_LAPLACIAN, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         } else {
             prm.t = 1.0f;
             prm.gscale = -1.0f;
             prm.clamp2 = 1e-8f;
-            launch_conv_d<GLHIP_ENERGY, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
+            if (use_mfma_dist(flags, n_ranges, B, D)) launch_dist_grad_d<GLHIP_ENERGY, DG_FWDGRAD, T>(prm, rg, n_ranges, N, M, D, sc, st);
+            else launch_conv_d<GLHIP_ENERGY, 2, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
         }
     };
     if (in_dtype == GLHIP_F32) run(float{}); else run(bf16_t{});

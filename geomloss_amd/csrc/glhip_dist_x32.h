@@ -90,10 +90,13 @@ __device__ __forceinline__ float min16(const f32x16& v) {
 // reduction of one 32 x 32 block: d2 (scaled squared distances), sb (per-column scalar, minus the running max for the soft-min)
 // CLAMP = false: the caller guarantees d2 >= clamp2 (see the near-pair logic of the kernel): |d2| only guards the square root
 // against a stray negative rounding residue (the absolute value is a free source modifier)
-template <bool CLAMP>
+// FAMILY: |.| = m rsq(m) instead of sqrt(m) — the expression of the product-and-gradient kernels (glhip_dist_grad_x32.h), for the
+// other terms of a kernel norm whose gradient is on (GLHIP_FLAG_GRAD_FAMILY)
+template <bool CLAMP, bool FAMILY = false>
 __device__ __forceinline__ float dist_of(float d2, float clamp2) {
     // v_med3_f32: the clamp in ONE instruction (fmaxf costs two: the compiler canonicalises the MFMA result first)
-    return CLAMP ? fast_sqrt(__builtin_amdgcn_fmed3f(d2, clamp2, 3.0e38f)) : fast_sqrt(__builtin_fabsf(d2));
+    const float m = CLAMP ? __builtin_amdgcn_fmed3f(d2, clamp2, 3.0e38f) : __builtin_fabsf(d2);
+    return FAMILY ? m * fast_rsq(m) : fast_sqrt(m);
 }
 
 template <int MODE, bool CLAMP = true>
@@ -112,7 +115,7 @@ __device__ __forceinline__ float block_sum(const f32x16& d2, const f32x16& sb, f
 // kernel products: the per-column weight read straight from LDS (4 broadcast ds_read_b128 per block) instead of a third MFMA —
 // 16 result registers and one operand less, which is what lets 8 waves per SIMD fit (<= 64 VGPRs; 4 records + 4 bytes per column
 // = 34 KiB of LDS per workgroup).  sg = &weights[first column of the group + 4 * half]: register k <-> column (k/4)*8 + 4*half + k%4.
-template <int MODE, bool CLAMP = true>
+template <int MODE, bool CLAMP = true, bool FAMILY = false>
 __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __restrict__ sg, float clamp2) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -121,7 +124,7 @@ __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __
         const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dist = dist_of<CLAMP>(d2[q * 4 + r], clamp2);
+            const float dist = dist_of<CLAMP, FAMILY>(d2[q * 4 + r], clamp2);
             if (MODE == DM_LAPLACIAN) acc[r] = __builtin_fmaf(fast_exp2(-dist), sv[r], acc[r]);
             else acc[r] = __builtin_fmaf(-dist, sv[r], acc[r]);
         }
@@ -129,9 +132,10 @@ __device__ __forceinline__ float block_sum_lds(const f32x16& d2, const float* __
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <int MODE, int D, typename T, int NW>
+template <int MODE, int D, typename T, int NW, bool FAMILY = false>
 __global__ void __launch_bounds__(NW * 64, MODE == DM_SOFTMIN_P1 ? 6 : 8)     // kernel products: 8 waves per SIMD (<= 64 VGPRs); soft-min: 6 (<= 80)
 dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    static_assert(!FAMILY || MODE != DM_SOFTMIN_P1, "FAMILY is a variant of the kernel products");
     constexpr int kRowsPerBlock = NW * 32;
     constexpr int kThreads = NW * 64;
     constexpr bool kWeightsInLds = MODE != DM_SOFTMIN_P1;
@@ -240,7 +244,8 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                 __syncthreads();
                 int near = 0;
                 for (int t = tid; t < npad; t += kThreads) {
-                    float ys[3] = {0.f, 0.f, 0.f}, n2 = 0.f, sj = (MODE == DM_SOFTMIN_P1) ? kNegBig : 0.f;
+                    // padding columns: zero weight; FAMILY: also infinitely far (0 * rsq(0) is not a number)
+                    float ys[3] = {0.f, 0.f, 0.f}, n2 = (FAMILY && t >= n) ? 1.0e30f : 0.f, sj = (MODE == DM_SOFTMIN_P1) ? kNegBig : 0.f;
                     if (t < n) {
                         float yj[D];
                         load_point<D, T>(prm.y, j0 + t, yj);
@@ -298,7 +303,7 @@ dist_x32_kernel(DistParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                             if (__any(min16(d2) < thr)) exact_near_pairs<D>(d2, thr, prm.clamp2, g, xs3, half);
                         }
                         if constexpr (kWeightsInLds) {
-                            st += block_sum_lds<MODE, CL>(d2, &weights[G * 32 + half * 4], prm.clamp2);
+                            st += block_sum_lds<MODE, CL, FAMILY>(d2, &weights[G * 32 + half * 4], prm.clamp2);
                         } else {
                             const f32x16 sb = mfma_x32(select_u4(half != 0, kZero, g[128 + l31]), Xs, zero16);
                             st += block_sum<MODE, CL>(d2, sb, prm.clamp2);

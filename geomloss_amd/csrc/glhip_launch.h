@@ -17,6 +17,7 @@
 #include "glhip_softmin_x32.h"
 #include "glhip_wsum_x32.h"
 #include "glhip_dist_x32.h"
+#include "glhip_dist_grad_x32.h"
 #include "glhip_softmin_xd.h"
 #include "glhip_wsum_t32.h"
 
@@ -302,7 +303,7 @@ inline float dist_guard() {   // GLHIP_DIST_GUARD: test knob (1e30 = every pair 
     return g;
 }
 
-template <int MODE, int D, typename T, class MergeOp>
+template <int MODE, int D, typename T, class MergeOp, bool FAMILY = false>
 void launch_dist(const DistParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int N, int M,
                  const Scratch& sc, hipStream_t st) {
     unsigned chunk_grid = 0;
@@ -315,9 +316,41 @@ void launch_dist(const DistParams<T>& prm, const typename MergeOp::Params& mprm,
     sp.split_stride = (long)N * MergeOp::kPartial;
     sp.xcd_grid_x = 0;
     sp.xcd_blocks = 0;
-    hipLaunchKernelGGL((dist_x32_kernel<MODE, D, T, kDistNW>), dim3(chunk_grid, 1, sp.n_splits), dim3(kDistNW * 64), 0, st, prm, rgc, N, M, sp);
+    hipLaunchKernelGGL((dist_x32_kernel<MODE, D, T, kDistNW, FAMILY>), dim3(chunk_grid, 1, sp.n_splits), dim3(kDistNW * 64), 0, st, prm, rgc, N, M, sp);
     if (sp.n_splits > 1)
         hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
+}
+
+// laplacian / energy product + gradient (GM = DG_FWDGRAD) or gradient (DG_BWD) on matrix-core distances (glhip_dist_grad_x32.h);
+// MergeOp = ConvOp<KIND, D, 1, T, 2 | 1>: same partial formats as the direct-difference operators
+template <int KIND, int GM, int D, typename T>
+void launch_dist_grad(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int N, int M, const Scratch& sc, hipStream_t st) {
+    using MergeOp = ConvOp<KIND, D, 1, T, GM == DG_FWDGRAD ? 2 : 1>;
+    DistGradParams<T> gp;
+    gp.d = DistParams<T>{prm.x, prm.y, prm.v, nullptr, nullptr, prm.out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
+    gp.g = prm.g;
+    gp.gx = prm.gx;
+    gp.gscale = prm.gscale;
+    unsigned chunk_grid = 0;
+    const Ranges rgc = with_row_chunks(rg, n_ranges, N, kDistNW * 32, sc.cb, st, chunk_grid);
+    const long per_split = (long)N * MergeOp::kPartial * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(n_ranges, M, n_ranges, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)N * MergeOp::kPartial;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    hipLaunchKernelGGL((dist_grad_x32_kernel<KIND, GM, D, T, kDistNW>), dim3(chunk_grid, 1, sp.n_splits), dim3(kDistNW * 64), 0, st, gp, rgc, N, M, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+}
+
+template <int KIND, int GM, typename T>
+void launch_dist_grad_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges, int N, int M, int D, const Scratch& sc, hipStream_t st) {
+    if (D == 1) launch_dist_grad<KIND, GM, 1, T>(prm, rg, n_ranges, N, M, sc, st);
+    else if (D == 2) launch_dist_grad<KIND, GM, 2, T>(prm, rg, n_ranges, N, M, sc, st);
+    else launch_dist_grad<KIND, GM, 3, T>(prm, rg, n_ranges, N, M, sc, st);
 }
 
 // ---- 4 <= D <= 16 on the matrix cores (glhip_softmin_xd.h): soft-min forward / fused half-step (MODE XD_SOFTMIN) and gaussian
@@ -380,13 +413,13 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
 }
 
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
-template <int MODE, int D, typename T, class MergeOp>
-void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
+template <int MODE, int D, typename T, class MergeOp, int RT>
+void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                      int M, const Scratch& sc, hipStream_t st) {
     constexpr int kPart = (MODE == WS_GAUSS_BWD) ? D : D + 1;
     static_assert(MergeOp::kPartial == kPart, "partial formats differ");
     static_assert(kMfmaRowsPerBlock == kBlock * MergeOp::kRows, "merge kernel and main kernel must tile rows alike");
-    constexpr int RT = (D <= 8) ? 2 : 1, NW = 8 / RT;       // 256 rows per workgroup either way; 2 row tiles share the LDS reads
+    constexpr int NW = 8 / RT;       // 256 rows per workgroup either way
     unsigned chunk_grid = 0;
     const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kMfmaRowsPerBlock, sc.cb, st, chunk_grid) : rg;
     const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kMfmaRowsPerBlock - 1) / kMfmaRowsPerBlock);
@@ -420,6 +453,16 @@ void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& m
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     }
+}
+
+template <int MODE, int D, typename T, class MergeOp>
+void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
+                     int M, const Scratch& sc, hipStream_t st) {
+    // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8; beyond, the x-side
+    // operands of two tiles no longer fit 128 VGPRs: 8 wavefronts x 32 rows.  GLHIP_T32_RT=1: test knob (1 tile for every D).
+    static const int forced = getenv("GLHIP_T32_RT") ? atoi(getenv("GLHIP_T32_RT")) : 0;
+    if (D <= 8 && forced != 1) launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1)>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    else launch_wsum_t32_rt<MODE, D, T, MergeOp, 1>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
 
 // soft-min gradient (and value + gradient) through the transposed kernel
@@ -728,15 +771,23 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.gscale = -1.0f / blur;
             prm.clamp2 = 1e-8f * kLog2e * kLog2e;   // the reference clamps |x/blur - y/blur|^2
             if constexpr (!BWD) {
+                if (use_mfma_dist(flags, n_ranges, B, D)) {      // GRAD_FAMILY: |.| = m rsq(m), as the product of glhip_dist_grad_x32.h
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
+                    const bool fam = (flags & GLHIP_FLAG_GRAD_FAMILY) != 0;
+#define GL_DIST(DD) \
+    if (fam) launch_dist<DM_LAPLACIAN, DD, T, ConvOp<GLHIP_LAPLACIAN, DD, 1, T, false>, true>(dp, prm, rg, n_ranges, N, M, sc, st); \
+    else launch_dist<DM_LAPLACIAN, DD, T, ConvOp<GLHIP_LAPLACIAN, DD, 1, T, false>, false>(dp, prm, rg, n_ranges, N, M, sc, st)
+                    if (D == 1) { GL_DIST(1); } else if (D == 2) { GL_DIST(2); } else { GL_DIST(3); }
+#undef GL_DIST
+                    return GLHIP_OK;
+                }
                 if (flags & GLHIP_FLAG_GRAD_FAMILY) {   // rounded like the product-and-gradient kernel (glhip_kconv_ops.h, MODE 3)
                     launch_conv_d<GLHIP_LAPLACIAN, 3, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
                     return GLHIP_OK;
                 }
+            } else {
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
-                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, prm.t, prm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
-                    if (D == 1) launch_dist<DM_LAPLACIAN, 1, T, ConvOp<GLHIP_LAPLACIAN, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
-                    else if (D == 2) launch_dist<DM_LAPLACIAN, 2, T, ConvOp<GLHIP_LAPLACIAN, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
-                    else launch_dist<DM_LAPLACIAN, 3, T, ConvOp<GLHIP_LAPLACIAN, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    launch_dist_grad_d<GLHIP_LAPLACIAN, DG_BWD, T>(prm, rg, n_ranges, N, M, D, sc, st);
                     return GLHIP_OK;
                 }
             }
@@ -746,15 +797,23 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.gscale = -1.0f;
             prm.clamp2 = 1e-8f;
             if constexpr (!BWD) {
+                if (use_mfma_dist(flags, n_ranges, B, D)) {
+                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f, dist_guard()};
+                    const bool fam = (flags & GLHIP_FLAG_GRAD_FAMILY) != 0;
+#define GL_DIST(DD) \
+    if (fam) launch_dist<DM_ENERGY, DD, T, ConvOp<GLHIP_ENERGY, DD, 1, T, false>, true>(dp, prm, rg, n_ranges, N, M, sc, st); \
+    else launch_dist<DM_ENERGY, DD, T, ConvOp<GLHIP_ENERGY, DD, 1, T, false>, false>(dp, prm, rg, n_ranges, N, M, sc, st)
+                    if (D == 1) { GL_DIST(1); } else if (D == 2) { GL_DIST(2); } else { GL_DIST(3); }
+#undef GL_DIST
+                    return GLHIP_OK;
+                }
                 if (flags & GLHIP_FLAG_GRAD_FAMILY) {   // rounded like the product-and-gradient kernel (glhip_kconv_ops.h, MODE 3)
                     launch_conv_d<GLHIP_ENERGY, 3, T>(prm, rg, n_ranges, B, N, M, D, sc, st);
                     return GLHIP_OK;
                 }
+            } else {
                 if (use_mfma_dist(flags, n_ranges, B, D)) {
-                    DistParams<T> dp{prm.x, prm.y, v, nullptr, nullptr, out, 1.f, 1e-8f, 1.f, 0.f, 1.f, 0.f, dist_guard()};
-                    if (D == 1) launch_dist<DM_ENERGY, 1, T, ConvOp<GLHIP_ENERGY, 1, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
-                    else if (D == 2) launch_dist<DM_ENERGY, 2, T, ConvOp<GLHIP_ENERGY, 2, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
-                    else launch_dist<DM_ENERGY, 3, T, ConvOp<GLHIP_ENERGY, 3, 1, T, false>>(dp, prm, rg, n_ranges, N, M, sc, st);
+                    launch_dist_grad_d<GLHIP_ENERGY, DG_BWD, T>(prm, rg, n_ranges, N, M, D, sc, st);
                     return GLHIP_OK;
                 }
             }

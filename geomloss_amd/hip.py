@@ -760,17 +760,25 @@ class _KernelConv(torch.autograd.Function):
         # (D <= 3: every kernel; 4 <= D <= 16: the gaussian kernel on the matrix cores)
         fused = (_fuse_kernel_grad and ctx.needs_input_grad[1]
                  and (xb.shape[-1] <= 3 or (kind == GAUSSIAN and xb.shape[-1] <= XD_MAX_DIM and not (flags & FLAG_NO_MFMA))))
-        plan = None if fused or kind == GAUSSIAN or (flags & FLAG_GRAD_FAMILY) else compact_rows_plan(xb, yb, ranges, flags)
-        if fused:
-            out, unit = kernel_conv_fwd_grad_raw(kind, xb, yb, vb, blur, ranges, flags)
-        elif plan is not None:     # large dense laplacian / energy product: voxel-sorted rows, distances from the matrix cores
-            out, unit = plan.unsort(kernel_conv_fwd_raw(kind, plan.x, plan.y, plan.cols(vb), blur, plan.ranges, flags | FLAG_MFMA_DIST)), None
+        # laplacian / energy: squared distances from the matrix cores wherever the row blocks are spatially compact — the voxel
+        # clusters of the multiscale backend as they are, large dense launches after a voxel sort of both clouds (plan) — for the
+        # product, the product + gradient and (GRAD_FAMILY) the companion products of a norm alike
+        plan, fl = None, flags
+        if kind != GAUSSIAN and _dist_on_mfma and xb.shape[-1] <= 3 and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+            if ranges is not None:
+                fl |= FLAG_MFMA_DIST
+            else:
+                plan = compact_rows_plan(xb, yb, ranges, flags)
+        if plan is not None:
+            X, Y, V, R, fl = plan.x, plan.y, plan.cols(vb), plan.ranges, fl | FLAG_MFMA_DIST
         else:
-            fl = flags
-            if (kind in (LAPLACIAN, ENERGY) and ranges is not None and _dist_on_mfma
-                    and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT | FLAG_GRAD_FAMILY))):
-                fl |= FLAG_MFMA_DIST               # multiscale: the row blocks are voxel clusters already
-            out, unit = kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, fl), None
+            X, Y, V, R = xb, yb, vb, ranges
+        if fused:
+            out, unit = kernel_conv_fwd_grad_raw(kind, X, Y, V, blur, R, fl)
+        else:
+            out, unit = kernel_conv_fwd_raw(kind, X, Y, V, blur, R, fl), None
+        if plan is not None:
+            out, unit = plan.unsort(out), (None if unit is None else plan.unsort(unit))
         ctx.unit = unit
         ctx.save_for_backward(xb, yb, vb)
         ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)

@@ -620,3 +620,75 @@ def test_empty_clouds(cuda):
     assert torch.isposinf(hip.softmin(0.1, x, y0, h0, flags=hip.FLAG_NO_MFMA)).all()
     assert (hip.kernel_conv("gaussian", x, y0, h0, 0.3) == 0).all()
     assert (hip.kernel_conv("energy", x, y0, h0, 0.3) == 0).all()
+
+
+@pytest.mark.parametrize("N,M,D", [(6000, 7000, 3), (3000, 2500, 2), (900, 1100, 1)])
+def test_distance_kernel_gradients_on_the_matrix_cores_block_sparse(cuda, N, M, D):
+    """glhip_dist_grad_x32.h on cluster-sorted clouds (GLHIP_FLAG_MFMA_DIST): laplacian / energy product + unit gradient in one
+    pass, gradient alone, and the FAMILY product (|.| = m rsq(m)) that accompanies them, against the C oracle with the same
+    ranges.  A few coincident points: inside the clamp the product sees the floor, the gradient nothing."""
+    voxel = 0.12 if D == 3 else 0.05
+    xs, ys, rg, tup = _clustered(17 + D, N, M, D, cuda, voxel)
+    ys[:5] = xs[:5]
+    x, y = xs.cpu().numpy(), ys.cpu().numpy()
+    rng = np.random.default_rng(5)
+    v = (rng.random(M) / M).astype(np.float32)
+    v[::5] *= -1
+    g = rng.standard_normal(N).astype(np.float32)
+    fl = hip.FLAG_MFMA_DIST
+    for kind, code, blur in (("laplacian", hip.LAPLACIAN, 0.07), ("energy", hip.ENERGY, 1.0)):
+        ref = oracle_c.kconv(kind, x, y, v, blur, ranges=tup)
+        bound = oracle_c.kconv(kind, x, y, np.abs(v), blur, ranges=tup)
+        refg = oracle_c.kconv_grad_x(kind, x, y, v, g, blur, ranges=tup)
+        refu = oracle_c.kconv_grad_x(kind, x, y, v, np.ones(N), blur, ranges=tup)
+        out, unit = hip.kernel_conv_fwd_grad_raw(code, xs[None], ys[None], _t(v, cuda)[None], blur, rg, fl)
+        assert np.abs(out[0].cpu().numpy() - ref).max() < 5e-6 * np.abs(bound).max(), kind
+        tolg = 2e-5 if D > 1 else 5e-5        # on a line, x_i S0 - S1 is the difference of two one-sided sums
+        assert relerr(unit[0].cpu().numpy(), refu) < tolg, kind
+        gx = hip.kernel_conv_bwd_x_raw(code, xs[None], ys[None], _t(v, cuda)[None], _t(g, cuda)[None], blur, rg, fl)
+        assert relerr(gx[0].cpu().numpy(), refg) < tolg, kind
+        fam = hip.kernel_conv_fwd_raw(code, xs[None], ys[None], _t(v, cuda)[None], blur, rg, fl | hip.FLAG_GRAD_FAMILY)[0]
+        assert np.abs(fam.cpu().numpy() - ref).max() < 5e-6 * np.abs(bound).max(), kind
+        # the product of the fused kernel and the FAMILY product share their arithmetic (same distances, |.| = m rsq(m)); only the
+        # order of the sums differs
+        assert (fam - out[0]).abs().max().item() < 2e-6 * np.abs(bound).max(), kind
+        # without a workspace (no column splits, one workgroup per row block): raw C-ABI call
+        lib = hip.load_library()
+        o2, u2 = torch.empty((1, N), device=cuda), torch.empty((1, N, D), device=cuda)
+        vt = _t(v, cuda)[None].contiguous()
+        rc = lib.glhip_kernel_conv_fwd_grad(code, xs.data_ptr(), ys.data_ptr(), vt.data_ptr(), o2.data_ptr(), u2.data_ptr(), 1, N, M, D,
+                                            blur, hip.F32, *rg.c_args(), None, 0, fl, None)
+        torch.cuda.synchronize()
+        assert rc == 0 and np.abs(o2[0].cpu().numpy() - ref).max() < 5e-6 * np.abs(bound).max()
+        assert relerr(u2[0].cpu().numpy(), refu) < tolg
+
+
+def test_distance_kernel_losses_dense_large_launches(cuda):
+    """SamplesLoss("energy" | "laplacian", backend="online") with gradients at a size where the three products of the norm take the
+    sorted matrix-core route (product + gradient for the terms in x, FAMILY product for the y-y term): loss, dL/dx, dL/da against
+    the float64 oracle.  ``shift``: a loss of the size of its terms, everything at 1e-4.  Same law: the loss is 1e-5 (energy) to
+    1e-3 (laplacian) of its three terms, each an fp32 sum — it is judged on the scale of those terms (1e-7: their rounding must
+    be COMMON to cancel; the first version of the fused kernel lost 1.7e-5 of a product to a single running accumulator)."""
+    from geomloss_amd import SamplesLoss
+    from oracle import oracle_torch64 as o64
+    N = M = 70_000
+    g = torch.Generator().manual_seed(12)
+    x, y0 = torch.rand(N, 3, generator=g).to(cuda), torch.rand(M, 3, generator=g).to(cuda)
+    for name, blur, shift in (("energy", None, False), ("laplacian", 0.05, False), ("energy", None, True), ("laplacian", 0.05, True)):
+        y = y0 * 0.6 + 0.3 if shift else y0
+        ref, rgx, rga = o64.kernel_loss(name, x, y, blur=0.05 if blur is None else blur, grad=True, device=cuda)
+        xg = x.clone().requires_grad_(True)
+        a = torch.full((N,), 1.0 / N, device=cuda, requires_grad=True)
+        b = torch.full((M,), 1.0 / M, device=cuda)
+        kw = {} if blur is None else dict(blur=blur)
+        L = SamplesLoss(name, backend="online", **kw)(a, xg, b, y)
+        gx, ga = torch.autograd.grad(L, [xg, a])
+        e = (abs(L.item() - ref) / abs(ref), relerr(gx.cpu().numpy(), rgx), relerr(ga.cpu().numpy(), rga))
+        term = abs(float(o64.kconv(name, x, x, np.full(N, 1.0 / N), 0.05 if blur is None else blur, device=cuda).mean()))   # <a, K_xx a>
+        print(f"{name} 7e4 shift={shift}: loss {L.item():.6e} oracle {ref:.6e} rel {e[0]:.2e} (terms ~{term:.1e}); dL/dx rel {e[1]:.2e}; "
+              f"dL/da rel {e[2]:.2e}")
+        assert e[1] < 1e-4
+        if shift:
+            assert e[0] < 1e-4 and e[2] < 1e-4
+        else:
+            assert abs(L.item() - ref) < 2e-7 * max(term, abs(ref))
