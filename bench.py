@@ -24,8 +24,9 @@ A *pair* is one evaluation of exp(h_j - C(x_i,y_j)/eps) inside one soft-min redu
   peak = 256 CU x 4 SIMD x 2.4 GHz x 64 pairs / 10 cycles = 1.573e13 pairs/s.  ``achieved`` = pairs per launch /
   mean launch duration measured here with HIP events on the launch stream.  The dense-equivalent HBM figure that
   BASELINE.json asks for (4 algorithmic bytes per pair) is kept in ``hbm_dense_equivalent``; it
-  exceeds 1 because the kernel never streams that matrix.  ``traffic`` is null: HBM counters cannot be read inside
-  this process; the rocprofv3 PMC summary of this same command is quoted under ``builder_pmc`` with its source.
+  exceeds 1 because the kernel never streams that matrix.  ``traffic`` = HBM bytes per launch of the dominant kernel from two
+  rocprofv3 PMC passes that this process runs over a minimal copy of its own command (``measure_traffic``; null if the
+  profiler is not there); the builder's fuller PMC summary of the same command stays under ``builder_pmc`` with its source.
 * cpu_baseline (rank 0, N = 1): PyTorch-CPU port of the reference's tensorized Sinkhorn
   (oracle/tensorized_torch.py, pinned to the reference by tests/test_oracle_golden.py::test_torch_port_matches_reference)
   on BASELINE configs[0] exactly (N=M=2000, 2D, fp32) and at N=M=5000 3D.
@@ -55,7 +56,7 @@ VALU_PEAK_PAIRS_PER_S = SIMDS * CLOCK_HZ * 64 / NOMINAL_CYCLES_PER_64_PAIRS
 # measured on this part (tools/ubench, profiles/r01_ubench_pipes.txt): that exp2 + add stream alone runs at 12.5
 # cycles per 64 pairs (v_exp_f32 8.2-9.7, v_add_f32 2.5-3.1), the kernel's bare inner loop (MFMA pair + stream) at 13.5
 MEASURED_STREAM_CYCLES = 12.5
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_softmin.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_softmin.json")
 
 
 def log(*a):
@@ -128,6 +129,51 @@ def cpu_baseline(budget_s=10.0):
         "n5000_3d": {"value": v5, "unit": "pairs/s", "seconds": t5, "runs": n5, "softmin_calls": c5},
         "note": "tensorized cannot run at N=1e6 (4 TB per cost matrix): no CPU number exists for the headline size",
     }
+
+
+def measure_traffic(points, timeout_s=120):
+    """HBM traffic of the dominant kernel, measured HERE: two `rocprofv3 --pmc <counter> --kernel-trace` passes (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over a minimal run of this very command
+    (`bench.py --no-extras`: warm-up + 2 timed launches).  Counters are KiB per dispatch, averaged over the launches of
+    softmin_fwd_x32_kernel; FETCH_SIZE is doubled (gfx950 counts the 128-byte requests of a wide coalesced read at 64 bytes: the
+    guide's correction — our column loads are such reads, the doubled figure is the upper estimate).  Returns a dict or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = tempfile.mkdtemp(prefix="glhip_pmc_", dir="/tmp")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras", "--points", str(points)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("WORLD_SIZE", None)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                con = sqlite3.connect(db)
+                rows = con.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                                   "group by kernel_name, counter_name").fetchall()
+                for k, cn, n, avg, dur in rows:
+                    if "softmin_fwd_x32_kernel" in k and cn == counter:
+                        got[counter] = {"kib_per_launch": avg, "launches": n, "kernel_ns_under_profiler": dur}
+        if "FETCH_SIZE" not in got or "WRITE_SIZE" not in got:
+            return None
+        f, w = got["FETCH_SIZE"]["kib_per_launch"], got["WRITE_SIZE"]["kib_per_launch"]
+        return {"bytes_per_launch": (2.0 * f + w) * 1024.0, "bytes_per_launch_uncorrected": (f + w) * 1024.0, "counters": got,
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, two passes over `bench.py --no-extras`, run by this "
+                          "process; softmin_fwd_x32_kernel only (the pack and merge kernels of the same call move 64 + 125 MB more)"}
+    except Exception as e:      # a profiler hiccup must not cost the bench line
+        log(f"[bench] traffic leg failed: {e!r}")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def hot_path_kernels(dev, n=1_000_000):
@@ -329,6 +375,12 @@ def run_headline(args, dev):
         },
     }
     if not args.no_extras:
+        if not args.no_traffic:
+            t = measure_traffic(n)
+            if t is not None:
+                res["roofline"]["traffic"] = t["bytes_per_launch"]
+                res["roofline"]["traffic_detail"] = t
+                log(f"[bench] HBM traffic of the dominant kernel (PMC, this run): {t['bytes_per_launch'] / 1e6:.0f} MB per launch")
         for key, fn in (("kernels", lambda: hot_path_kernels(dev, n)), ("cpu_baseline", cpu_baseline),
                         ("sinkhorn_wallclock", lambda: sinkhorn_wallclock(dev)),
                         ("sharded_batch_reference", lambda: sharded_reference(dev))):
@@ -443,7 +495,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=1_000_000, help="N = M of the soft-min workload (N = 1)")
     ap.add_argument("--batch", type=int, default=256, help="global batch of the sharded workload (N > 1)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side legs (kernels, cpu_baseline, wall-clocks)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs (traffic, kernels, cpu_baseline, wall-clocks)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU dry run)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 (batch-sharded) leg even with one rank: exercises process-group init + the RCCL all-reduce on a 1-GPU box")

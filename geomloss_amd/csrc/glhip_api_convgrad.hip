@@ -52,10 +52,6 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
 #define GL_XD(DD) launch_gauss_grad_t32<DD, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st)
                 GLHIP_XD_DISPATCH(D, GL_XD)
 #undef GL_XD
-            } else if (flags & GLHIP_FLAG_T32) {
-                if (D == 1) launch_gauss_grad_t32<1, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                else if (D == 2) launch_gauss_grad_t32<2, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                else launch_gauss_grad_t32<3, true, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
             }
             else if (D == 1) launch_gauss_fwdgrad<1, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
             else if (D == 2) launch_gauss_fwdgrad<2, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);

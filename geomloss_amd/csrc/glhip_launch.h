@@ -458,11 +458,9 @@ void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params
 template <int MODE, int D, typename T, class MergeOp>
 void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                      int M, const Scratch& sc, hipStream_t st) {
-    // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8; beyond, the x-side
-    // operands of two tiles no longer fit 128 VGPRs: 8 wavefronts x 32 rows.  GLHIP_T32_RT=1: test knob (1 tile for every D).
-    static const int forced = getenv("GLHIP_T32_RT") ? atoi(getenv("GLHIP_T32_RT")) : 0;
-    if (D <= 8 && forced != 1) launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1)>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
-    else launch_wsum_t32_rt<MODE, D, T, MergeOp, 1>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8 — measured 3-16 % faster
+    // than 1 tile there (profiles/r03_grad_kernels_ab.txt); beyond, the x-side operands of two tiles no longer fit 128 VGPRs
+    launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1)>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
 
 // soft-min gradient (and value + gradient) through the transposed kernel
@@ -636,14 +634,6 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
                 return GLHIP_OK;
             }
         }
-        if constexpr (BWD) {
-            if (p == 2 && mfma && !direct && (flags & GLHIP_FLAG_T32)) {      // transposed 32x32x16 gradient kernel (glhip_wsum_t32.h)
-                if (D == 1) launch_softmin_bwd_t32<1, T>(prm, rg, n_ranges, B, N, M, sc, st);
-                else if (D == 2) launch_softmin_bwd_t32<2, T>(prm, rg, n_ranges, B, N, M, sc, st);
-                else launch_softmin_bwd_t32<3, T>(prm, rg, n_ranges, B, N, M, sc, st);
-                return GLHIP_OK;
-            }
-        }
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
@@ -750,14 +740,6 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
             prm.t = std::sqrt(0.5f * kLog2e) / blur;
             prm.gscale = -1.0f / (prm.t * blur * blur);
             prm.clamp2 = 0.f;
-            if constexpr (BWD) {
-                if ((flags & GLHIP_FLAG_NO_MFMA) == 0 && (flags & GLHIP_FLAG_T32)) {
-                    if (D == 1) launch_gauss_grad_t32<1, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                    else if (D == 2) launch_gauss_grad_t32<2, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                    else launch_gauss_grad_t32<3, false, T>(prm, blur, rg, n_ranges, B, N, M, sc, st);
-                    return GLHIP_OK;
-                }
-            }
             if ((flags & GLHIP_FLAG_NO_MFMA) == 0) {
                 const bool x32 = (flags & GLHIP_FLAG_XDL16) == 0;
                 if (D == 1) launch_gauss_mfma<1, BWD, T>(prm, blur, rg, n_ranges, B, N, M, sc, x32, st);

@@ -13,7 +13,9 @@
 // the lane's half: register k <-> column (k / 4) * 8 + 4 * half + k % 4) — 4 (D + 1) ds_read_b128 per 32-column group, shared by the
 // RT row tiles of the wavefront.  Per 1024 pairs and row tile: NM MFMAs, 16 v_exp_f32, 16 (D + 1) v_fma_f32 / v_add_f32.
 //
-// Used for 4 <= D <= 16 (before: the one-thread-per-row VALU kernel of glhip_generic.h) and, behind GLHIP_FLAG_T32, for D <= 3.
+// Used for 4 <= D <= 16 (before: the one-thread-per-row VALU kernel of glhip_generic.h).  For D <= 3 it was measured against the
+// 16x16x32 kernel and is no faster (soft-min gradient at 1e6: 158 vs 148 ms; gaussian gradient 159 vs 163 ms;
+// profiles/r03_grad_kernels_ab.txt): 126 VGPRs = 4 waves per SIMD, where the 16x16x32 kernel runs 5 — the D <= 3 gradients stay there.
 #pragma once
 
 #include "glhip_softmin_xd.h"

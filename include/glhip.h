@@ -74,10 +74,6 @@ extern "C" {
                                  (~2^-24 (rho + d)^2 / d on a potential, rho = row-block diameter) when row blocks are spatially compact:
                                  the caller's responsibility (voxel clusters of the multiscale backends, voxel-sorted dense clouds). */
 
-#define GLHIP_FLAG_T32 128 /* soft-min gradient / gaussian gradient / product + gradient, D <= 3: the transposed 32x32x16 kernel
-                                 (glhip_wsum_t32.h: one row per lane, D + 1 accumulators) instead of the 16x16x32 one.  4 <= D <= 16 always
-                                 run on it. */
-
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
  *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
