@@ -82,7 +82,24 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
 
     for (int row0 = row_begin; row0 < row_end; row0 += kMfmaRowsPerBlock) {
         float centre[D];
-        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+        if (MODE == WS_SOFTMIN_BWD) {
+            load_point<D, T>(prm.x, (long)b * N + row0, centre);     // SoftminBwdOp::merge_row works relative to this very point
+        } else {
+            // gaussian modes (their partials do not depend on the centre): the mean of 8 rows of the block.  The error of an expanded
+            // exponent grows with |x - c|^2 + |y - c|^2; for an unsorted cloud "the first row" is a random point of the cloud
+            // (offsets up to a diameter), a mean of 8 sits near its middle — half the error on the gradient of an MMD at 1e6
+            // (tests/test_full_size_gpu.py::test_cfg5_*: 9.7e-5 -> 4e-5 of the budget of 1e-4); for sorted clouds it is the
+            // natural centre of the row block.
+#pragma unroll
+            for (int d = 0; d < D; ++d) centre[d] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float pt[D];
+                load_point<D, T>(prm.x, (long)b * N + min(row0 + k * (kMfmaRowsPerBlock / 8), row_end - 1), pt);
+#pragma unroll
+                for (int d = 0; d < D; ++d) centre[d] += 0.125f * pt[d];
+            }
+        }
         const int wave_row0 = row0 + wave * kMfmaRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
 

@@ -338,8 +338,8 @@ def test_kernel_product_and_gradient_in_one_pass(cuda, kind, N, M, D, B):
     if B is None:
         ref = oracle_c.kconv_grad_x(kind, xb.detach().float().cpu().numpy(), yb.float().cpu().numpy(), v, g, blur)
         assert relerr(gb.float().cpu().numpy(), ref) < 2.0 ** -7
-    with pytest.raises(NotImplementedError):
-        hip.kernel_conv_fwd_grad_raw(code, _t(np.zeros((1, 8, 4), np.float32), cuda), _t(np.zeros((1, 8, 4), np.float32), cuda),
+    with pytest.raises(NotImplementedError):      # one-pass kernels: D <= 3 (gaussian: D <= 16, tests/test_xd_kernels_gpu.py)
+        hip.kernel_conv_fwd_grad_raw(code, _t(np.zeros((1, 8, 17), np.float32), cuda), _t(np.zeros((1, 8, 17), np.float32), cuda),
                                      _t(np.zeros((1, 8), np.float32), cuda), blur)
 
 
