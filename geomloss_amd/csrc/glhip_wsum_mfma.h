@@ -82,24 +82,12 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
 
     for (int row0 = row_begin; row0 < row_end; row0 += kMfmaRowsPerBlock) {
         float centre[D];
-        if (MODE == WS_SOFTMIN_BWD) {
-            load_point<D, T>(prm.x, (long)b * N + row0, centre);     // SoftminBwdOp::merge_row works relative to this very point
-        } else {
-            // gaussian modes (their partials do not depend on the centre): the mean of 8 rows of the block.  The error of an expanded
-            // exponent grows with |x - c|^2 + |y - c|^2; for an unsorted cloud "the first row" is a random point of the cloud
-            // (offsets up to a diameter), a mean of 8 sits near its middle — half the error on the gradient of an MMD at 1e6
-            // (tests/test_full_size_gpu.py::test_cfg5_*: 9.7e-5 -> 4e-5 of the budget of 1e-4); for sorted clouds it is the
-            // natural centre of the row block.
-#pragma unroll
-            for (int d = 0; d < D; ++d) centre[d] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float pt[D];
-                load_point<D, T>(prm.x, (long)b * N + min(row0 + k * (kMfmaRowsPerBlock / 8), row_end - 1), pt);
-#pragma unroll
-                for (int d = 0; d < D; ++d) centre[d] += 0.125f * pt[d];
-            }
-        }
+        // (A centre nearer the middle of the cloud — the mean of 8 rows of the block — halves the offsets of an unsorted cloud and was
+        // tried for the gaussian modes in round 3 to widen the margin of the 1e6-point MMD gradient (9.7e-5 of a budget of 1e-4):
+        // the same-law LOSS of that test went from 2.1e-5 to 2.6e-4 of the float64 value — the three terms of the norm are a
+        // difference of 1e-3 of their size and owe their agreement to a common rounding pattern, which a per-block mean disturbs.
+        // The first row it stays.)
+        load_point<D, T>(prm.x, (long)b * N + row0, centre);
         const int wave_row0 = row0 + wave * kMfmaRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
 
