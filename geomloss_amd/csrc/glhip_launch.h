@@ -559,7 +559,34 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     sp.xcd_blocks = 0;
     m.ws_stride = (long)sp.n_splits * B * maxN * 2;
     const int gx = (maxN + kRows - 1) / kRows;
-    hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    // Pre-packed columns (as in launch_softmin_mfma_nw): with 128-row workgroups every column is split into its bf16 pieces
+    // (maxN / 128) times per problem; one more small launch does it once.  Measured (round 3): B x 4096^2 bf16 with B = 128 / 64 / 32
+    // (the 2- / 4- / 8-GPU shards of configs[3]): 8.65 -> 8.28, 4.54 -> 4.35, 2.43 -> 2.32 ms per loss; N = M = 3e4: 4.07 -> 3.84 ms;
+    // N = M = 1e4 and below: no difference (0.9 ms).
+    double pairs = 0.0;
+    int maxM = 0;
+    for (int k = 0; k < m.count; ++k) {
+        pairs += (double)B * m.N[k] * m.M[k];
+        maxM = m.M[k] > maxM ? m.M[k] : maxM;
+        m.pk[k] = PackedCols{nullptr, (long)((m.M[k] + 31) / 32) * 128};
+    }
+    static const double pre_min = getenv("GLHIP_ITER4_PRE_MIN") ? atof(getenv("GLHIP_ITER4_PRE_MIN")) : 1e8;   // tuning knob
+    bool pre = sc.ws && sc.allow_split && pairs >= pre_min;
+    if (pre) {
+        size_t off = (((size_t)(sp.n_splits > 1 ? m.count : 0) * (size_t)m.ws_stride * sizeof(float)) + 255) & ~(size_t)255;
+        for (int k = 0; k < m.count && pre; ++k) {
+            const size_t bytes = (size_t)B * (size_t)m.pk[k].stride * sizeof(uint4);
+            if (off + bytes > sc.bytes) { pre = false; break; }
+            m.pk[k].rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + off);
+            off += (bytes + 255) & ~(size_t)255;
+        }
+    }
+    if (pre) {
+        hipLaunchKernelGGL((pack_columns_multi_kernel<D, T>), dim3((maxM + 31 + kBlock) / kBlock, B, m.count), dim3(kBlock), 0, st, m);
+        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, true>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    } else {
+        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, false>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    }
     if (sp.n_splits > 1)
         hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
 }

@@ -377,9 +377,23 @@ struct SoftminMulti {
     int N[4], M[4];
     long ws_stride;     // floats of split workspace per problem
     int count;
+    PackedCols pk[4];   // PRE launches: the packed columns of every problem (pack_columns_multi_kernel)
 };
 
-template <int D, typename T, int NW>
+// the columns of all the problems of a multi launch as packed records, once (grid: column blocks x batch x problem)
+template <int D, typename T>
+__global__ void __launch_bounds__(kBlock)
+pack_columns_multi_kernel(SoftminMulti<T> m) {
+    const int k = blockIdx.z, b = blockIdx.y;
+    const int N = m.N[k], M = m.M[k];
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (N == 0 || j >= ((M + 31) & ~31)) return;
+    float centre[D];
+    load_point<D, T>(m.p[k].x, (long)b * N, centre);
+    pack_column<D, T>(m.p[k], (long)b * M + j, j < M, centre, m.pk[k].rec + b * m.pk[k].stride + (j >> 5) * 128 + (j & 31), 32);
+}
+
+template <int D, typename T, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
     __shared__ uint4 tileX[kTileX * 4];
@@ -390,8 +404,8 @@ softmin_fwd_x32_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
     SplitInfo spk = sp;
     spk.workspace += k * m.ws_stride;
     spk.split_stride = (long)gridDim.y * N * 2;   // this problem's own row count
-    softmin_fwd_x32_body<D, T, false, 1, NW, false>(m.p[k], Ranges{nullptr, nullptr, nullptr}, N, M, spk, PackedCols{nullptr, 0},
-                                                    (int)blockIdx.x, (int)blockIdx.y, split, tileX);
+    softmin_fwd_x32_body<D, T, false, 1, NW, PRE>(m.p[k], Ranges{nullptr, nullptr, nullptr}, N, M, spk, m.pk[k],
+                                                  (int)blockIdx.x, (int)blockIdx.y, split, tileX);
 }
 
 template <class Op, typename T>

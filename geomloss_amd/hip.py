@@ -429,7 +429,8 @@ def _serpentine(perm, xs, ranges, cents, voxel):
     sizes = (ranges[:, 1] - ranges[:, 0]).long()[order]
     starts = ranges[:, 0].long()[order]
     offs = torch.cumsum(sizes, 0) - sizes                                   # first row of every cluster in the new order
-    idx = torch.repeat_interleave(starts - offs, sizes) + torch.arange(xs.shape[0], device=xs.device)
+    # output_size: spares repeat_interleave the host round trip it would otherwise make to learn sum(sizes)
+    idx = torch.repeat_interleave(starts - offs, sizes, output_size=xs.shape[0]) + torch.arange(xs.shape[0], device=xs.device)
     return perm[idx], xs[idx]
 
 
