@@ -267,6 +267,7 @@ def sinkhorn_wallclock(dev):
     run("online_1e5_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, True)
     run("gaussian_online_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, False, reps=1)
     run("gaussian_online_1e6_fwd_bwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, True, reps=1)
+    run("energy_online_1e6_fwd", SamplesLoss("energy", backend="online"), 1_000_000, False, reps=1)
     run("energy_online_1e6_fwd_bwd", SamplesLoss("energy", backend="online"), 1_000_000, True, reps=1)
     run("gaussian_multiscale_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="multiscale"), 1_000_000, False, reps=1)
 

@@ -434,6 +434,14 @@ def _serpentine(perm, xs, ranges, cents, voxel):
     return perm[idx], xs[idx]
 
 
+def compact_order(x, rows_per_voxel=None):
+    """(perm, x[perm]): the cloud x (N,D) voxel-sorted (``glhip_grid_cluster``, ~rows_per_voxel points per voxel) with the voxels
+    chained along the boustrophedon path of :func:`_serpentine` — any run of consecutive rows is spatially compact."""
+    voxel = _voxel_for(x, _DIST_ROWS_PER_VOXEL if rows_per_voxel is None else rows_per_voxel)
+    perm, xs, _, ranges, cents, _ = grid_cluster_raw(x.contiguous(), None, voxel)
+    return _serpentine(perm.long(), xs, ranges, cents, voxel)
+
+
 class _CompactRows:
     """Spatially sorted copies of the two clouds of a dense launch + the block-sparse pattern "every slab of 256 rows x all
     columns" (in a few column chunks, so that the column splits of the launch have something to split).  Both clouds are sorted
@@ -446,11 +454,8 @@ class _CompactRows:
     def __init__(self, xb, yb):
         x, y = xb[0], yb[0]
         N, M = x.shape[0], y.shape[0]
-        vx, vy = _voxel_for(x, _DIST_ROWS_PER_VOXEL), _voxel_for(y, 2 * _DIST_ROWS_PER_VOXEL)
-        perm, xs, _, ranges, cents, _ = grid_cluster_raw(x.contiguous(), None, vx)
-        self.perm, xs = _serpentine(perm.long(), xs, ranges, cents, vx)
-        perm_y, ys, _, ranges_y, cents_y, _ = grid_cluster_raw(y.contiguous(), None, vy)
-        self.perm_y, ys = _serpentine(perm_y.long(), ys, ranges_y, cents_y, vy)
+        self.perm, xs = compact_order(x, _DIST_ROWS_PER_VOXEL)
+        self.perm_y, ys = compact_order(y, 2 * _DIST_ROWS_PER_VOXEL)
         self.x, self.y = xs.unsqueeze(0).contiguous(), ys.unsqueeze(0).contiguous()
         C = (N + _DIST_SLAB - 1) // _DIST_SLAB
         first = torch.arange(C, device=x.device, dtype=torch.int32) * _DIST_SLAB

@@ -246,3 +246,43 @@ def test_multiscale_variants_match_two_scale_oracle(cuda, kw):
     assert torch.isfinite(gx).all()
     if balanced:   # p = 1: unit directions from fp32 differences, same bound as the kernel-level test
         assert relerr(gx.cpu().numpy(), ref_gx) < 1e-4, relerr(gx.cpu().numpy(), ref_gx)
+
+
+@pytest.mark.parametrize("name", ["gaussian", "laplacian", "energy"])
+def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name):
+    """No gradient, no potentials, big clouds: the two self-terms of a kernel norm are evaluated over the upper triangle of
+    their symmetric matrices (kernel_samples._self_term_value: two block-sparse launches, half the pairs).  Same value as the
+    float64 oracle and as the full products (the path taken when gradients are on), weighted measures, N not a multiple of 256."""
+    import geomloss_amd.kernel_samples as ks
+    from oracle import oracle_torch64 as o64
+    g = torch.Generator().manual_seed(21)
+    N, M = 50_001, 46_000
+    x, y = torch.rand(N, 3, generator=g).to(cuda), (torch.rand(M, 3, generator=g) * 0.8 + 0.1).to(cuda)
+    a, b = torch.rand(N, generator=g).to(cuda) + 0.5, torch.rand(M, generator=g).to(cuda) + 0.5
+    a, b = a / a.sum(), b / b.sum()
+    calls = []
+    orig = ks._self_term_value
+    monkeypatch.setattr(ks, "_self_term_value", lambda *args: (calls.append(1), orig(*args))[1])
+    loss = SamplesLoss(name, blur=0.05, backend="online")
+    L_half = loss(a, x, b, y)
+    assert len(calls) == 2 and L_half.shape == ()
+    xg = x.clone().requires_grad_(True)
+    L_full = loss(a, xg, b, y)                         # gradients on: the three full products
+    assert len(calls) == 2
+    ref = o64.kernel_loss(name, x, y, a, b, blur=0.05, device=cuda)
+    # the loss is a difference of three terms of this size, each good to a few float32 ulps
+    tol = 1e-4 * abs(ref) + 3e-7 * {"energy": 1.0, "laplacian": 0.05, "gaussian": 0.01}[name]
+    assert abs(L_half.item() - ref) < tol, (L_half.item(), ref)
+    assert abs(L_half.item() - L_full.item()) < tol, (L_half.item(), L_full.item())
+    with torch.no_grad():                              # autograd switched off: value only, whatever the inputs carry
+        assert abs(loss(a, xg, b, y).item() - L_half.item()) < 1e-7 * abs(ref) and len(calls) == 4
+    F, G = SamplesLoss(name, blur=0.05, backend="online", potentials=True)(a, x, b, y)      # potentials: full products
+    assert len(calls) == 4 and F.numel() == N
+    xb, yb = torch.rand(2, 40_000, 3, generator=g).to(cuda), torch.rand(2, 40_000, 3, generator=g).to(cuda)
+    ks_min = ks._UPPER_MIN_PAIRS
+    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 1e9)
+    assert loss(xb, yb).shape == (2,) and len(calls) == 4                                         # batches: full products
+    L1 = loss(xb[:1], yb[:1])
+    assert L1.shape == (1,) and len(calls) == 6                                                   # a batch of one: upper triangle
+    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", ks_min)
+    assert abs(L1.item() - loss(xb, yb)[0].item()) < tol                # two samples of one law: term-sized tolerance
