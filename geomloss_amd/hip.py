@@ -757,14 +757,15 @@ class _KernelConv(torch.autograd.Function):
     """out_i = sum_j k(x_i,y_j) v_j, differentiable in x, y and v."""
 
     @staticmethod
-    def forward(ctx, kind, x, y, v, blur, ranges, flags):
+    def forward(ctx, kind, x, y, v, blur, ranges, flags, x_grad=True):
         xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
         # carries one more accumulator, the product itself.  The backward pass is then elementwise.
         # (D <= 3: every kernel; 4 <= D <= 16: the gaussian kernel on the matrix cores)
-        fused = (_fuse_kernel_grad and ctx.needs_input_grad[1]
+        # x_grad: needs_input_grad says True for a leaf that requires gradients even under no_grad, where nothing will be asked for
+        fused = (_fuse_kernel_grad and x_grad and ctx.needs_input_grad[1]
                  and (xb.shape[-1] <= 3 or (kind == GAUSSIAN and xb.shape[-1] <= XD_MAX_DIM and not (flags & FLAG_NO_MFMA))))
         # laplacian / energy: squared distances from the matrix cores wherever the row blocks are spatially compact — the voxel
         # clusters of the multiscale backend as they are, large dense launches after a voxel sort of both clouds (plan) — for the
@@ -806,7 +807,7 @@ class _KernelConv(torch.autograd.Function):
             gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt, flags).reshape(ys).to(ydt)
         if ctx.needs_input_grad[3]:
             gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt, flags).reshape(vs).to(vdt)
-        return None, gx, gy, gv, None, None, None
+        return None, gx, gy, gv, None, None, None, None
 
 
 # product + row gradient in one pass when x requires gradients (GEOMLOSS_HIP_FUSE_GRAD=0: always two reductions)
@@ -825,7 +826,8 @@ def kernel_grad_fusion():
 def kernel_conv(kind, x, y, v, blur=0.05, ranges=None, flags=0):
     """Kernel-matrix x vector product on the GPU; ``kind`` is a name or a GLHIP_* code."""
     kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
-    return _KernelConv.apply(kind, x, y, v, 1.0 if blur is None else float(blur), ranges, int(flags) | ENV_FLAGS)
+    return _KernelConv.apply(kind, x, y, v, 1.0 if blur is None else float(blur), ranges, int(flags) | ENV_FLAGS,
+                             torch.is_grad_enabled() and x.requires_grad)
 
 
 class _SoftminDense(torch.autograd.Function):

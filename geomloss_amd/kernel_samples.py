@@ -78,6 +78,13 @@ def _matvec(K, v):
     return (K @ v.unsqueeze(-1)).squeeze(-1)
 
 
+def _family_flags(x, y):
+    """GRAD_FAMILY when one of the three products of the loss will run on a product-and-gradient kernel (see _kernel_operators)."""
+    if (x.shape[-1] <= 3 and torch.is_grad_enabled() and hip.kernel_grad_fusion() and (x.requires_grad or y.requires_grad)):
+        return hip.FLAG_GRAD_FAMILY
+    return 0
+
+
 def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
     """(K_xx, K_yy, K_xy).  Symmetric blocks differentiate through their first argument only, with a doubled
     gradient (kernel_samples.py:117-125)."""
@@ -94,10 +101,7 @@ def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
         # products of the same loss are then sent to the kernel of the same family (gaussian: 16x16x32 MFMA tiling, identical
         # exponent arithmetic; laplacian / energy: explicit differences with |.| = m rsq(m), bit-identical to the product of
         # the fused mode) so that the per-term rounding bias stays common to the three terms and cancels.
-        flags = 0
-        if (x.shape[-1] <= 3 and torch.is_grad_enabled() and hip.kernel_grad_fusion()
-                and (x.requires_grad or y.requires_grad)):
-            flags = hip.FLAG_GRAD_FAMILY
+        flags = _family_flags(x, y)
         build = lambda u, w, r: _LazyKernel(name, u, w, blur, r, flags)  # noqa: E731
     else:
         dense = kernel_routines[name] if kernel is None else kernel
@@ -105,11 +109,17 @@ def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
     return build(double_grad(x), x.detach(), r_xx), build(double_grad(y), y.detach(), r_yy), build(x, y, r_xy)
 
 
-# Self-terms over the upper triangle.  <a, K_xx a> is a symmetric quadratic form: when nothing but its VALUE is wanted (no
-# gradient flows, no potentials) the pairs (i, j) and (j, i) need not both be evaluated.  The rows are cut into blocks of 256 (the
-# row tile of the kernels); block I reduces once over its own columns (the diagonal block, both orientations inside it) and once
-# over the columns of the blocks after it, counted twice — two block-sparse launches of the ordinary product kernel, half the pair
-# evaluations of the dense product.  Gaussian MMD at N = M = 1e6, forward only: 3 reductions of 1e12 pairs become 2.
+# Self-terms over the upper triangle.  <a, K_xx a> is a symmetric quadratic form: when nothing but the VALUE of the loss is wanted
+# (no gradient flows, no potentials) the pairs (i, j) and (j, i) need not both be evaluated.  The rows are cut into blocks of 256
+# (the row tile of the kernels); block I reduces once over its own columns (the diagonal block, both orientations inside it) and
+# once over the columns of the blocks after it, counted twice — two block-sparse launches of the ordinary product kernel, half the
+# pair evaluations of the dense product.  Kernel norms at N = M = 1e6, forward only: 3 reductions of 1e12 pairs become 2.
+# The three dot products <a, .> and their combination are carried in float64 there (1e6 terms each; the loss between two samples
+# of one law is 1e-6 of its terms, a dozen float32 quanta of the energy distance's).
+# Not used when a gradient is wanted, even for the self-term of a measure that takes none: the three products of a loss then run
+# in one kernel family so that their common rounding bias (gaussian: -1.6e-5 relative, from the float32 accumulation of
+# exponent terms of size diam^2 / blur^2) cancels in the difference; a term evaluated another way would carry another bias
+# (measured: profiles/r03_upper_triangle.txt).
 _UPPER_BLOCK, _UPPER_CHUNKS, _UPPER_MIN_PAIRS = 256, 8, 2e9
 _UPPER_KERNELS = ("gaussian", "laplacian", "energy")
 
@@ -134,7 +144,7 @@ def _upper_triangle_patterns(N, device):
 
 
 def _self_term_value(name, x, w, blur):
-    """<w, K_xx w> for one un-batched cloud x (1,N,D)|(N,D) from the upper triangle; a 0-dim tensor.
+    """<w, K_xx w> for one un-batched cloud x (1,N,D)|(N,D) from the upper triangle, no autograd graph; a 0-dim float64 tensor.
     laplacian / energy: the cloud is first put in the compact order of hip.compact_order, so that the 256-row blocks are what the
     matrix-core distance kernels want (hip._KernelConv switches them on for block-sparse launches)."""
     xd = x.detach().reshape(-1, x.shape[-1])
@@ -146,12 +156,17 @@ def _self_term_value(name, x, w, blur):
     diag, upper = _upper_triangle_patterns(N, xd.device)
     d = hip.kernel_conv(name, xd, xd, wv, blur, ranges=diag)
     u = hip.kernel_conv(name, xd, xd, wv, blur, ranges=upper)
-    return (wv * (d + 2.0 * u)).sum()
+    return torch.dot(wv.double(), d.double() + 2.0 * u.double())
 
 
-def _value_only(α, x, β, y):
-    """Nothing will be differentiated: autograd is off, or no input carries a graph."""
-    return not torch.is_grad_enabled() or not any(t.requires_grad for t in (α, x, β, y))
+def _takes_no_gradient(w, pts):
+    return not (torch.is_grad_enabled() and (w.requires_grad or pts.requires_grad))
+
+
+def _upper_triangle_applies(name, w, pts):
+    """One un-batched cloud of dimension <= 3, big enough for the two block-sparse launches to pay."""
+    return (name in _UPPER_KERNELS and pts.shape[-1] <= 3 and float(pts.shape[-2]) ** 2 >= _UPPER_MIN_PAIRS
+            and (pts.dim() == 2 or pts.shape[0] == 1))
 
 
 def kernel_loss(
@@ -160,14 +175,16 @@ def kernel_loss(
 ):
     """Kernel norm 1/2 <α-β, k*(α-β)> or its potentials (``:92-146``).  ``use_keops=True`` selects the matrix-free
     HIP path (the keyword keeps the reference's name; no KeOps is involved)."""
-    B = x.shape[0] if x.dim() > 2 else 1
-    if (use_keops and not potentials and kernel is None and name in _UPPER_KERNELS and B == 1 and x.shape[-1] <= 3
-            and ranges_xx is None and ranges_yy is None and ranges_xy is None and _value_only(α, x, β, y)
-            and float(x.shape[-2]) ** 2 >= _UPPER_MIN_PAIRS and float(y.shape[-2]) ** 2 >= _UPPER_MIN_PAIRS):
+    batch = x.dim() > 2
+    if (use_keops and not potentials and kernel is None and ranges_xx is None and ranges_yy is None and ranges_xy is None
+            and _takes_no_gradient(α, x) and _takes_no_gradient(β, y)
+            and _upper_triangle_applies(name, α, x) and _upper_triangle_applies(name, β, y)):
         # value only, dense kernel norm on big clouds: the two symmetric self-terms over the upper triangle
-        cross = hip.kernel_conv(name, x.detach(), y.detach(), β.detach().reshape(y.shape[:-1]), blur)
-        out = 0.5 * (_self_term_value(name, x, α, blur) + _self_term_value(name, y, β, blur)) - (α.detach().reshape(x.shape[:-1]) * cross).sum()
-        return out.view(1) if x.dim() > 2 else out
+        xd, yd, bd = x.detach(), y.detach(), β.detach().reshape(y.shape[:-1])
+        cross = torch.dot(α.detach().reshape(-1).double(), hip.kernel_conv(name, xd, yd, bd, blur).reshape(-1).double())
+        out = (0.5 * (_self_term_value(name, x, α, blur) + _self_term_value(name, y, β, blur)) - cross).float()
+        return out.view(1) if batch else out
+
     K_xx, K_yy, K_xy = _kernel_operators(x, y, blur, kernel, name, use_keops, (ranges_xx, ranges_yy, ranges_xy))
 
     a_x = _matvec(K_xx, α.detach())  # (k * α)(x_i)
@@ -178,7 +195,6 @@ def kernel_loss(
         K_yx = K_xy.t() if use_keops else K_xy.transpose(-1, -2)
         return a_x - b_x, b_y - _matvec(K_yx, α)
 
-    batch = x.dim() > 2
     self_terms = scal(double_grad(α), a_x, batch=batch) + scal(double_grad(β), b_y, batch=batch)
     return 0.5 * self_terms - scal(α, b_x, batch=batch)
 

@@ -252,7 +252,8 @@ def test_multiscale_variants_match_two_scale_oracle(cuda, kw):
 def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name):
     """No gradient, no potentials, big clouds: the two self-terms of a kernel norm are evaluated over the upper triangle of
     their symmetric matrices (kernel_samples._self_term_value: two block-sparse launches, half the pairs).  Same value as the
-    float64 oracle and as the full products (the path taken when gradients are on), weighted measures, N not a multiple of 256."""
+    float64 oracle and as the full products (the path taken as soon as a gradient is wanted — there the three products stay in
+    one kernel family), weighted measures, N not a multiple of 256."""
     import geomloss_amd.kernel_samples as ks
     from oracle import oracle_torch64 as o64
     g = torch.Generator().manual_seed(21)
@@ -265,17 +266,19 @@ def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name
     monkeypatch.setattr(ks, "_self_term_value", lambda *args: (calls.append(1), orig(*args))[1])
     loss = SamplesLoss(name, blur=0.05, backend="online")
     L_half = loss(a, x, b, y)
-    assert len(calls) == 2 and L_half.shape == ()
-    xg = x.clone().requires_grad_(True)
-    L_full = loss(a, xg, b, y)                         # gradients on: the three full products
-    assert len(calls) == 2
+    assert len(calls) == 2 and L_half.shape == () and L_half.dtype == torch.float32
     ref = o64.kernel_loss(name, x, y, a, b, blur=0.05, device=cuda)
     # the loss is a difference of three terms of this size, each good to a few float32 ulps
     tol = 1e-4 * abs(ref) + 3e-7 * {"energy": 1.0, "laplacian": 0.05, "gaussian": 0.01}[name]
     assert abs(L_half.item() - ref) < tol, (L_half.item(), ref)
-    assert abs(L_half.item() - L_full.item()) < tol, (L_half.item(), L_full.item())
+
+    xg, ag = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    for args in ((a, xg, b, y), (ag, x, b, y), (a, x, b, y.clone().requires_grad_(True))):
+        L_full = loss(*args)                           # a gradient somewhere: the three full products, one kernel family
+        assert len(calls) == 2 and L_full.requires_grad
+        assert abs(L_half.item() - L_full.item()) < tol, (L_half.item(), L_full.item())
     with torch.no_grad():                              # autograd switched off: value only, whatever the inputs carry
-        assert abs(loss(a, xg, b, y).item() - L_half.item()) < 1e-7 * abs(ref) and len(calls) == 4
+        assert loss(a, xg, b, y).item() == L_half.item() and len(calls) == 4
     F, G = SamplesLoss(name, blur=0.05, backend="online", potentials=True)(a, x, b, y)      # potentials: full products
     assert len(calls) == 4 and F.numel() == N
     xb, yb = torch.rand(2, 40_000, 3, generator=g).to(cuda), torch.rand(2, 40_000, 3, generator=g).to(cuda)
@@ -286,3 +289,17 @@ def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name
     assert L1.shape == (1,) and len(calls) == 6                                                   # a batch of one: upper triangle
     monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", ks_min)
     assert abs(L1.item() - loss(xb, yb)[0].item()) < tol                # two samples of one law: term-sized tolerance
+
+
+def test_kernel_product_under_no_grad_skips_the_gradient_kernel(cuda):
+    """autograd.Function reports needs_input_grad = True for a leaf that requires gradients even under no_grad; the product must
+    then still come from the product kernel (same bits as for a plain tensor), not from the product-and-gradient kernel."""
+    g = torch.Generator().manual_seed(3)
+    x, y, v = torch.rand(3000, 3, generator=g).to(cuda), torch.rand(2500, 3, generator=g).to(cuda), torch.rand(2500, generator=g).to(cuda)
+    xg = x.clone().requires_grad_(True)
+    for name in ("gaussian", "laplacian", "energy"):
+        plain = hip.kernel_conv(name, x, y, v, 0.1)
+        with torch.no_grad():
+            assert torch.equal(hip.kernel_conv(name, xg, y, v, 0.1), plain)
+        out = hip.kernel_conv(name, xg, y, v, 0.1)
+        assert out.requires_grad and torch.allclose(out, plain, rtol=1e-4, atol=1e-6)
