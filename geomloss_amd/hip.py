@@ -753,6 +753,32 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     return out if batched else out.view(-1)
 
 
+# Gaussian reductions on the kernels that centre every workgroup on its own first row (the gradient kernels and the products of
+# their family, glhip_wsum_mfma.h): the exponent -|x - y|^2 / 2 blur^2 is assembled on the matrix cores from terms of size
+# |x - c| |y - c| / blur^2, and its float32 accumulation leaves a relative error of that size x 2^-24 in the kernel value — a
+# common bias of -1.6e-5 on every term of a norm at blur = .05 in the unit cube when the rows of a workgroup are scattered over
+# the cloud.  With the rows in compact order (256 neighbours per workgroup) |x - c| is the size of a voxel and the bias drops to
+# -1.2e-6 (profiles/r03_upper_triangle.txt).  Large dense launches only: the sort costs ~1 ms at 1e6 points.
+_GAUSS_SORT_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_GAUSS_SORT_MIN", "1e11"))
+
+
+def _gauss_compact_rows(kind, xb, M, ranges, flags):
+    """(perm, rows in compact order) for a big dense gaussian launch of the per-workgroup-centre kernels, or None."""
+    B, N, D = xb.shape
+    if (kind != GAUSSIAN or ranges is not None or B != 1 or D > 3 or float(N) * M < _GAUSS_SORT_MIN_PAIRS
+            or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
+        return None
+    perm, xs = compact_order(xb[0])
+    return perm, xs.unsqueeze(0).contiguous()
+
+
+def _unsort_rows(perm, t):
+    """(1, N, ...) in sorted row order -> original order."""
+    out = torch.empty_like(t)
+    out[0, perm] = t[0]
+    return out
+
+
 class _KernelConv(torch.autograd.Function):
     """out_i = sum_j k(x_i,y_j) v_j, differentiable in x, y and v."""
 
@@ -776,16 +802,23 @@ class _KernelConv(torch.autograd.Function):
                 fl |= FLAG_MFMA_DIST
             else:
                 plan = compact_rows_plan(xb, yb, ranges, flags)
+        rows = None
         if plan is not None:
             X, Y, V, R, fl = plan.x, plan.y, plan.cols(vb), plan.ranges, fl | FLAG_MFMA_DIST
         else:
             X, Y, V, R = xb, yb, vb, ranges
+            if fused or (flags & FLAG_GRAD_FAMILY):      # gaussian: the kernels with one centre per workgroup
+                rows = _gauss_compact_rows(kind, xb, yb.shape[1], ranges, flags)
+                if rows is not None:
+                    X = rows[1]
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, X, Y, V, blur, R, fl)
         else:
             out, unit = kernel_conv_fwd_raw(kind, X, Y, V, blur, R, fl), None
         if plan is not None:
             out, unit = plan.unsort(out), (None if unit is None else plan.unsort(unit))
+        elif rows is not None:
+            out, unit = _unsort_rows(rows[0], out), (None if unit is None else _unsort_rows(rows[0], unit))
         ctx.unit = unit
         ctx.save_for_backward(xb, yb, vb)
         ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
@@ -802,12 +835,26 @@ class _KernelConv(torch.autograd.Function):
             if ctx.unit is not None:
                 gx = (g.unsqueeze(-1) * ctx.unit).reshape(xs).to(xdt)
             else:
-                gx = kernel_conv_bwd_x_raw(kind, xb, yb, vb, g, blur, ranges, flags).reshape(xs).to(xdt)
+                gx = _KernelConv._row_gradient(kind, xb, yb, vb, g, blur, ranges, flags).reshape(xs).to(xdt)
         if ctx.needs_input_grad[2]:
-            gy = kernel_conv_bwd_x_raw(kind, yb, xb, g, vb, blur, rt, flags).reshape(ys).to(ydt)
+            gy = _KernelConv._row_gradient(kind, yb, xb, g, vb, blur, rt, flags).reshape(ys).to(ydt)
         if ctx.needs_input_grad[3]:
-            gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt, flags).reshape(vs).to(vdt)
+            rows = _gauss_compact_rows(kind, yb, xb.shape[1], rt, flags) if (flags & FLAG_GRAD_FAMILY) else None
+            if rows is not None:
+                gv = _unsort_rows(rows[0], kernel_conv_fwd_raw(kind, rows[1], xb, g, blur, rt, flags))
+            else:
+                gv = kernel_conv_fwd_raw(kind, yb, xb, g, blur, rt, flags)
+            gv = gv.reshape(vs).to(vdt)
         return None, gx, gy, gv, None, None, None, None
+
+    @staticmethod
+    def _row_gradient(kind, rows_pts, cols_pts, v, g, blur, ranges, flags):
+        """d/d rows of sum_i g_i sum_j k(rows_i, cols_j) v_j (g per row, v per column), big gaussian launches in compact row order."""
+        rows = _gauss_compact_rows(kind, rows_pts, cols_pts.shape[1], ranges, flags)
+        if rows is None:
+            return kernel_conv_bwd_x_raw(kind, rows_pts, cols_pts, v, g, blur, ranges, flags)
+        perm, X = rows
+        return _unsort_rows(perm, kernel_conv_bwd_x_raw(kind, X, cols_pts, v, g[:, perm].contiguous(), blur, ranges, flags))
 
 
 # product + row gradient in one pass when x requires gradients (GEOMLOSS_HIP_FUSE_GRAD=0: always two reductions)

@@ -297,6 +297,49 @@ def test_kernel_conv_grads_vs_oracle(cuda, kind, D):
         assert relerr(gv.cpu().numpy(), oracle_c.kconv(kind, y, x, g, blur)) < tol
 
 
+@pytest.mark.parametrize("D", [3, 2])
+def test_gaussian_gradient_family_in_compact_row_order(cuda, monkeypatch, D):
+    """Big dense gaussian launches of the kernels with one centre per workgroup (product + gradient, gradients, GRAD_FAMILY products)
+    get their rows in compact order first (hip._gauss_compact_rows; threshold lowered here): same results in the caller's order,
+    closer to the oracle — the exponent is assembled from terms of size |x - c| |y - c| / blur^2, c the workgroup's first row."""
+    N, M = 5000, 4100
+    x, y, v = _clouds(77 + D, N, M, D)
+    v = np.abs(v) / M
+    blur = 0.03                         # diam / blur ~ 50: the regime where the float32 exponent error shows
+    g = np.random.default_rng(6).standard_normal(N).astype(np.float32)
+    ref = dict(out=oracle_c.kconv("gaussian", x, y, v, blur), gx=oracle_c.kconv_grad_x("gaussian", x, y, v, g, blur),
+               gy=oracle_c.kconv_grad_x("gaussian", y, x, g, v, blur), gv=oracle_c.kconv("gaussian", y, x, g, blur))
+    sorts = []
+    orig = hip.compact_order
+    monkeypatch.setattr(hip, "compact_order", lambda *a, **k: (sorts.append(1), orig(*a, **k))[1])
+    err = {}
+    for tag, thr in (("scattered", 1e30), ("compact", 0.0)):
+        monkeypatch.setattr(hip, "_GAUSS_SORT_MIN_PAIRS", thr)
+        for fused in (True, False):
+            hip.set_kernel_grad_fusion(fused)
+            try:
+                n0 = len(sorts)
+                xt, yt, vt = (_t(a, cuda).requires_grad_(True) for a in (x, y, v))
+                out = hip.kernel_conv("gaussian", xt, yt, vt, blur, flags=hip.FLAG_GRAD_FAMILY)
+                gx, gy, gv = torch.autograd.grad(out, [xt, yt, vt], grad_outputs=_t(g, cuda))
+                assert (len(sorts) - n0 > 0) == (tag == "compact")
+            finally:
+                hip.set_kernel_grad_fusion(True)
+            got = dict(out=out.detach(), gx=gx, gy=gy, gv=gv)
+            err[tag, fused] = {k: relerr(t.cpu().numpy(), ref[k]) for k, t in got.items()}
+            print(tag, fused, {k: f"{e:.1e}" for k, e in err[tag, fused].items()})
+            assert max(err[tag, fused].values()) < (8e-5 if tag == "compact" else 1e-3), (tag, fused, err[tag, fused])
+    for fused in (True, False):
+        for k in ("out", "gx", "gy", "gv"):         # 5000 points: a workgroup's 256 rows still span a third of the cloud; 1e6: 1 / 26
+            assert err["compact", fused][k] < 0.5 * err["scattered", fused][k], (k, fused, err)
+    monkeypatch.setattr(hip, "_GAUSS_SORT_MIN_PAIRS", 0.0)
+    n0 = len(sorts)
+    hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur)                    # forward family: global centre, no sort
+    xb = _t(np.stack([x, x]), cuda).requires_grad_(True)
+    hip.kernel_conv("gaussian", xb, _t(np.stack([y, y]), cuda), _t(np.stack([v, v]), cuda), blur)     # batches: no sort
+    assert len(sorts) == n0
+
+
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("N,M,D,B", [(310, 270, 3, None), (1030, 70_001, 3, None), (257, 300, 2, 3), (90, 80, 1, None)])
 def test_kernel_product_and_gradient_in_one_pass(cuda, kind, N, M, D, B):

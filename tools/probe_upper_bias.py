@@ -12,7 +12,10 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 g = torch.Generator().manual_seed(13)
 x, y = torch.rand(n, 3, generator=g).to(dev), torch.rand(n, 3, generator=g).to(dev)
 a = torch.full((n,), 1.0 / n, device=dev)
-for name in ("gaussian", "laplacian", "energy"):
+if os.environ.get("SORT", "0") == "1":      # both clouds along the boustrophedon voxel path: the row blocks become spatially compact
+    x, y = hip.compact_order(x)[1].contiguous(), hip.compact_order(y)[1].contiguous()
+    print("clouds in compact order")
+for name in os.environ.get("KERNELS", "gaussian laplacian energy").split():
     ref = {}
     for tag, (p, q) in (("xx", (x, x)), ("yy", (y, y)), ("xy", (x, y))):
         ref[tag] = float((a.double().cpu().numpy() * o64.kconv(name, p, q, a, 0.05, device=dev)).sum())
@@ -20,8 +23,9 @@ for name in ("gaussian", "laplacian", "energy"):
         out = {}
         for tag, (p, q) in (("xx", (x, x)), ("yy", (y, y)), ("xy", (x, y))):
             out[tag] = (a * hip.kernel_conv(name, p, q, a, 0.05, flags=flags)).double().sum().item()
-        for tag, p in (("xx", x), ("yy", y)):
-            out[tag + "_upper"] = ks._self_term_value(name, p, a, 0.05, flags).double().item()
+        if flags == 0:      # the upper-triangle path runs in the forward family only
+            for tag, p in (("xx", x), ("yy", y)):
+                out[tag + "_upper"] = ks._self_term_value(name, p, a, 0.05).double().item()
         xg = x.clone().requires_grad_(True)
         out["xy_fused"] = (a * hip.kernel_conv(name, xg, y, a, 0.05, flags=flags)).double().sum().item()
         out["xx_fused"] = (a * hip.kernel_conv(name, xg, x, a, 0.05, flags=flags)).double().sum().item()
