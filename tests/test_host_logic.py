@@ -268,6 +268,69 @@ def test_kernel_norm_sends_its_three_products_to_one_arithmetic(monkeypatch):
     assert {f for _, f, _ in seen} == {0}
 
 
+def test_upper_triangle_patterns_cover_each_unordered_block_pair_once():
+    """kernel_samples._upper_triangle_patterns: the diagonal pattern holds exactly the pairs of a 256-row block with itself, the
+    upper pattern exactly the pairs (i, j) with j in a LATER block — together every unordered pair of rows once (diagonal blocks:
+    both orientations), which is what `a . (d + 2 u)` needs.  Pure index logic: checked on the CPU with a dense mask."""
+    from geomloss_amd import kernel_samples as ks
+
+    for N in (1, 77, 256, 257, 1000, 5000):
+        diag, upper = ks._upper_triangle_patterns(N, torch.device("cpu"))
+        blk = torch.arange(N) // ks._UPPER_BLOCK
+        for pat, want in ((diag, blk[:, None] == blk[None, :]), (upper, blk[None, :] > blk[:, None])):
+            mask = torch.zeros(N, N, dtype=torch.int32)
+            first = 0
+            assert pat.ranges_i.shape[0] == pat.slices_i.shape[0] == (N + ks._UPPER_BLOCK - 1) // ks._UPPER_BLOCK
+            for (i0, i1), last in zip(pat.ranges_i.tolist(), pat.slices_i.tolist()):
+                for j0, j1 in pat.redranges_j[first:last].tolist():
+                    assert 0 <= j0 <= j1 <= N and (j0 == j1 or j0 % 32 == 0 or j0 == i1)
+                    mask[i0:i1, j0:j1] += 1
+                first = last
+            assert first == pat.redranges_j.shape[0] and torch.equal(mask, want.int()), N
+
+
+def test_kernel_norm_value_only_launches(monkeypatch):
+    """No gradient anywhere + big clouds: cross product + (diagonal, upper) launches per self-term, default kernel family, float64
+    combination; any gradient, potentials, batches, user ranges or small clouds: the three full products.  Launches recorded, not run."""
+    from geomloss_amd import kernel_samples as ks
+
+    seen = []
+
+    def record(kind, x, y, v, blur=0.05, ranges=None, flags=0):
+        seen.append((kind, ranges is not None, int(flags)))
+        return torch.ones(x.shape[:-1], dtype=torch.float32) * v.sum() + 0 * x.sum(-1)
+
+    monkeypatch.setattr(hip, "kernel_conv", record)
+    monkeypatch.setattr(hip, "compact_order", lambda pts: (torch.arange(pts.shape[0]), pts))
+    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 0.0)
+    x, y = torch.rand(300, 3), torch.rand(280, 3)
+    a, b = torch.full((300,), 1 / 300), torch.full((280,), 1 / 280)
+    for name in ("gaussian", "laplacian", "energy"):
+        seen.clear()
+        L = ks.kernel_online(a, x, b, y, blur=0.1, name=name)
+        assert [r for _, r, _ in seen] == [False, True, True, True, True] and {f for _, _, f in seen} == {0}
+        assert L.dtype == torch.float32 and L.shape == () and abs(L.item() - 2.0) < 1e-5    # 1/2 (3 + 3) - 1: every stand-in product is 1, a . (d + 2 u) = 3
+        assert ks.kernel_online(a[None], x[None], b[None], y[None], blur=0.1, name=name).shape == (1,)
+        for kw in (dict(potentials=True), dict(ranges_xy=object())):
+            seen.clear()
+            try:
+                ks.kernel_online(a, x, b, y, blur=0.1, name=name, **kw)
+            except Exception:
+                pass
+            assert seen and not any(r and kw.get("potentials") for _, r, _ in seen) and len(seen) <= 4
+        for args in ((a, x.clone().requires_grad_(True), b, y), (a, x, b.clone().requires_grad_(True), y)):
+            seen.clear()
+            ks.kernel_online(*args, blur=0.1, name=name)
+            assert len(seen) == 3 and not any(r for _, r, _ in seen)
+        seen.clear()
+        ks.kernel_online(a.expand(2, -1), x.expand(2, -1, -1), b.expand(2, -1), y.expand(2, -1, -1), blur=0.1, name=name)
+        assert len(seen) == 3
+    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 2e9)
+    seen.clear()
+    ks.kernel_online(a, x, b, y, blur=0.1, name="gaussian")
+    assert len(seen) == 3 and not any(r for _, r, _ in seen)
+
+
 # ---- C-ABI ------------------------------------------------------------------------------------------
 
 def test_shared_library_exports_every_declared_symbol():
