@@ -55,4 +55,25 @@ __device__ __forceinline__ void load_point(const T* __restrict__ p, long idx, fl
     for (int d = 0; d < D; ++d) o[d] = to_f32<T>(p[idx * D + d]);
 }
 
+// The one centre of a launch whose columns are packed once for all row blocks (pre-packed records, glhip_softmin_x32.h /
+// glhip_wsum_x32.h): the mean of 8 rows spread evenly over batch item b.  The float32 error of an exponent assembled on the matrix
+// cores grows with |x - c| |y - c|, so the centre should sit in the middle of the cloud whatever the order of the
+// points: a single row (round 2: the first one) is a CORNER of the cloud as soon as the caller's points are sorted — a grid, a
+// voxel-sorted scan — and costs 2-4 x the error of a central point.  Every kernel of a launch must compute the same bits: fixed
+// order of additions, a power-of-two count.
+template <int D, typename T>
+__device__ __forceinline__ void launch_centre(const T* __restrict__ x, int b, int N, float (&c)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {       // rows (2k + 1) N / 16: the middles of 8 equal runs (N < 8: some rows twice — still a row mean)
+        float p[D];
+        load_point<D, T>(x, (long)b * N + (((long)(2 * k + 1) * N) >> 4), p);
+#pragma unroll
+        for (int d = 0; d < D; ++d) c[d] += p[d];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] *= 0.125f;
+}
+
 }  // namespace glhip

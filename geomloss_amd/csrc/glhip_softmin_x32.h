@@ -92,10 +92,10 @@ __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long co
 }
 
 // Packed column records for a whole launch (PRE mode of the kernel below): launches with enough work split every
-// column once here instead of once per row pass of every workgroup.  One centre per batch item (its first row): for
-// unsorted clouds a workgroup's own first row is an equally arbitrary point; for cluster-sorted clouds (block-sparse
-// mode) the per-workgroup centre of the on-the-fly path is more accurate, the global one has the accuracy of the
-// dense launches (absolute error of a potential ~ 2^-23 diam^2, independent of eps).
+// column once here instead of once per row pass of every workgroup.  One centre per batch item (launch_centre: the mean of 8
+// rows spread over it): for unsorted clouds a workgroup's own first row is a more arbitrary point than that; for
+// cluster-sorted clouds (block-sparse mode) the per-workgroup centre of the on-the-fly path is more accurate, the global one
+// has the accuracy of the dense launches (absolute error of a potential ~ 2^-24 diam^2, independent of eps).
 struct PackedCols {
     uint4* rec;     // dense launches (GROUPED): [B][ceil(M/32)][4 K blocks][32 columns] — the LDS tile layout, so a tile
                     //   (which starts on a group boundary there) is staged by a linear, fully coalesced copy;
@@ -110,7 +110,7 @@ pack_columns_kernel(SoftminParams<T> prm, int N, int M, PackedCols pk) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= (GROUPED ? ((M + 31) & ~31) : M)) return;
     float centre[D];
-    load_point<D, T>(prm.x, (long)b * N, centre);
+    launch_centre<D, T>(prm.x, b, N, centre);
     if (GROUPED) pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31), 32);
     else pack_column<D, T>(prm, (long)b * M + j, true, centre, pk.rec + ((long)b * M + j) * 4, 1);
 }
@@ -194,7 +194,8 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
-        load_point<D, T>(prm.x, (long)b * N + (PRE ? 0 : row0), centre);
+        if (PRE) launch_centre<D, T>(prm.x, b, N, centre);
+        else load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
         const int wave_row0 = row0 + wave * kRowsPerWave;
         uint4 Xlo[RT], Xhi[RT];
@@ -389,7 +390,7 @@ pack_columns_multi_kernel(SoftminMulti<T> m) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (N == 0 || j >= ((M + 31) & ~31)) return;
     float centre[D];
-    load_point<D, T>(m.p[k].x, (long)b * N, centre);
+    launch_centre<D, T>(m.p[k].x, b, N, centre);
     pack_column<D, T>(m.p[k], (long)b * M + j, j < M, centre, m.pk[k].rec + b * m.pk[k].stride + (j >> 5) * 128 + (j & 31), 32);
 }
 

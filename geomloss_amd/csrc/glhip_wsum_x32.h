@@ -68,7 +68,7 @@ wsum_pack_kernel(WsumParams<T> prm, int N, int M, PackedCols pk, PackedQ pq) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= (GROUPED ? ((M + 31) & ~31) : M)) return;
     float centre[D];
-    load_point<D, T>(prm.x, (long)b * N, centre);
+    launch_centre<D, T>(prm.x, b, N, centre);
     float rec[4], qv[NQ];
     wsum_column<MODE, D, T>(prm, (long)b * M + j, j < M, centre, rec, qv);
     uint4* base = GROUPED ? pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31) : pk.rec + ((long)b * M + j) * 4;
@@ -116,7 +116,8 @@ wsum_x32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, Packed
 
     for (int row0 = row_begin; row0 < row_end; row0 += kMfmaRowsPerBlock) {
         float centre[D];
-        load_point<D, T>(prm.x, (long)b * N + (PRE ? 0 : row0), centre);
+        if (PRE) launch_centre<D, T>(prm.x, b, N, centre);
+        else load_point<D, T>(prm.x, (long)b * N + row0, centre);
         const int wave_row0 = row0 + wave * 32;
         const bool wave_active = wave_row0 < row_end;
 
