@@ -178,11 +178,19 @@ def kernel_loss(
     batch = x.dim() > 2
     if (use_keops and not potentials and kernel is None and ranges_xx is None and ranges_yy is None and ranges_xy is None
             and _takes_no_gradient(α, x) and _takes_no_gradient(β, y)
-            and _upper_triangle_applies(name, α, x) and _upper_triangle_applies(name, β, y)):
-        # value only, dense kernel norm on big clouds: the two symmetric self-terms over the upper triangle
-        xd, yd, bd = x.detach(), y.detach(), β.detach().reshape(y.shape[:-1])
-        cross = torch.dot(α.detach().reshape(-1).double(), hip.kernel_conv(name, xd, yd, bd, blur).reshape(-1).double())
-        out = (0.5 * (_self_term_value(name, x, α, blur) + _self_term_value(name, y, β, blur)) - cross).float()
+            and (_upper_triangle_applies(name, α, x) or _upper_triangle_applies(name, β, y)) and (not batch or x.shape[0] == 1)):
+        # value only, dense kernel norm with a big cloud: its symmetric self-term over the upper triangle (a small one: the full product)
+        def product(u, v, w):       # <a, K_uv w> in float64
+            k = hip.kernel_conv(name, u.detach(), v.detach(), w.detach().reshape(v.shape[:-1]), blur)
+            return k.reshape(-1).double()
+
+        def self_term(pts, w):
+            if _upper_triangle_applies(name, w, pts):
+                return _self_term_value(name, pts, w, blur)
+            return torch.dot(w.detach().reshape(-1).double(), product(pts, pts, w))
+
+        cross = torch.dot(α.detach().reshape(-1).double(), product(x, y, β))
+        out = (0.5 * (self_term(x, α) + self_term(y, β)) - cross).float()
         return out.view(1) if batch else out
 
     K_xx, K_yy, K_xy = _kernel_operators(x, y, blur, kernel, name, use_keops, (ranges_xx, ranges_yy, ranges_xy))

@@ -325,6 +325,10 @@ def test_kernel_norm_value_only_launches(monkeypatch):
         seen.clear()
         ks.kernel_online(a.expand(2, -1), x.expand(2, -1, -1), b.expand(2, -1), y.expand(2, -1, -1), blur=0.1, name=name)
         assert len(seen) == 3
+    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 300.0 ** 2)     # x (300 points) is "big", y (280) is not: one upper triangle, one full product
+    seen.clear()
+    L = ks.kernel_online(a, x, b, y, blur=0.1, name="gaussian")
+    assert [r for _, r, _ in seen] == [False, True, True, False] and abs(L.item() - 1.0) < 1e-5        # 1/2 (3 + 1) - 1
     monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 2e9)
     seen.clear()
     ks.kernel_online(a, x, b, y, blur=0.1, name="gaussian")

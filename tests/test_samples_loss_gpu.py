@@ -279,6 +279,13 @@ def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name
         assert abs(L_half.item() - L_full.item()) < tol, (L_half.item(), L_full.item())
     with torch.no_grad():                              # autograd switched off: value only, whatever the inputs carry
         assert loss(a, xg, b, y).item() == L_half.item() and len(calls) == 4
+    ys, bs = y[:3000].contiguous(), b[:3000] / b[:3000].sum()      # a big cloud against a small one: one upper triangle, one full product
+    n0 = len(calls)
+    L_mixed = loss(a, x, bs, ys)
+    assert len(calls) == n0 + 1
+    ref_mixed = o64.kernel_loss(name, x, ys, a, bs, blur=0.05, device=cuda)
+    assert abs(L_mixed.item() - ref_mixed) < 1e-4 * abs(ref_mixed) + tol, (L_mixed.item(), ref_mixed)
+    calls.pop()
     F, G = SamplesLoss(name, blur=0.05, backend="online", potentials=True)(a, x, b, y)      # potentials: full products
     assert len(calls) == 4 and F.numel() == N
     xb, yb = torch.rand(2, 40_000, 3, generator=g).to(cuda), torch.rand(2, 40_000, 3, generator=g).to(cuda)
