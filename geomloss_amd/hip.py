@@ -402,8 +402,10 @@ def set_distance_on_mfma(enabled):
 def _voxel_for(x, rows_per_voxel):
     """Voxel edge that puts ~rows_per_voxel points in an occupied voxel, from the bounding box of the (N, D) cloud."""
     N, D = x.shape
-    xf = x.float()
-    ext = [float(e) for e in (xf.amax(0) - xf.amin(0)).tolist()]
+    # reduce along the contiguous axis of a (D, N) copy: torch's reduction over dim 0 of a row-major (N, 3) tensor runs at 25 GB/s
+    # (0.8 ms for the two of them at 1e6 points, as long as the voxel sort they prepare)
+    lo, hi = torch.aminmax(x.detach().float().t().contiguous(), dim=1)
+    ext = [float(e) for e in (hi - lo).tolist()]
     live = [e for e in ext if e > 1e-6 * max(max(ext), 1e-30)]                     # axes the cloud really extends along
     vol = 1.0
     for e in live:
