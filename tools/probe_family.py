@@ -2,7 +2,7 @@
 <a, K_xx a>, <b, K_yy b>, <a, K_xy b> for the laplacian / energy kernels at N = M = n."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from geomloss_amd import hip
 from oracle import oracle_hip64
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 300_000
