@@ -65,6 +65,15 @@ CASES = {
     "energy_d3": (dict(loss="energy"), 13, 0, 190, 230, 3, True),
     "gaussian_batch": (dict(loss="gaussian", blur=0.2), 14, 2, 100, 120, 3, True),
     "gaussian_d6": (dict(loss="gaussian", blur=0.3), 15, 0, 90, 100, 6, True),
+    # round 3: the D = 4 ... 16 matrix-core kernels, the distance kernels with weights / in a batch, p = 1 with a reach
+    "sinkhorn_p2_d8": (dict(loss="sinkhorn", p=2, blur=0.2), 18, 0, 120, 100, 8, True),
+    "sinkhorn_p2_d16": (dict(loss="sinkhorn", p=2, blur=0.3), 19, 0, 110, 130, 16, True),
+    "gaussian_d12": (dict(loss="gaussian", blur=0.5), 20, 0, 100, 90, 12, True),
+    "laplacian_d3": (dict(loss="laplacian", blur=0.1), 21, 0, 210, 190, 3, True),
+    "energy_d2": (dict(loss="energy"), 22, 0, 180, 200, 2, True),
+    "laplacian_batch": (dict(loss="laplacian", blur=0.2), 23, 2, 110, 100, 3, True),
+    "sinkhorn_p1_reach_d2": (dict(loss="sinkhorn", p=1, blur=0.05, reach=0.5), 24, 0, 170, 190, 2, True),
+    "sinkhorn_p1_batch": (dict(loss="sinkhorn", p=1, blur=0.05, diameter=1.8), 25, 2, 100, 120, 3, True),
     # mid-size cases: what pins the chunked full-size oracle (oracle/oracle_torch64.py) beyond the sizes NumPy handles
     "sinkhorn_p2_n8000": (dict(loss="sinkhorn", p=2, blur=0.05), 16, 0, 8000, 7000, 3, True),
     "gaussian_n8000": (dict(loss="gaussian", blur=0.05), 17, 0, 8000, 7000, 3, True),
