@@ -23,15 +23,16 @@ __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, c, 0, 0, 0);
 }
 
-template <int VARIANT, int NQ, int NW>
+template <int VARIANT, int NQ, int NW, int RT = 2>
 __global__ void __launch_bounds__(NW * 64) kern(const uint4* __restrict__ rec, const float4* __restrict__ q, float* out, int M) {
     __shared__ uint4 tile[kTile * 4];
     __shared__ __attribute__((aligned(16))) float tileQ[4 * kTile];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31, rec0 = half * 32 + l31;
-    uint4 X[2][2];
-    for (int rt = 0; rt < 2; ++rt)
+    uint4 X[RT][2];
+    for (int rt = 0; rt < RT; ++rt)
         for (int m = 0; m < 2; ++m) X[rt][m] = uint4{0x3c003c00u + lane + rt, 0x3c003c00u + m, 0x3b003b00u, 0x3a003a00u + blockIdx.x % 7};
-    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float acc[RT][4];
+    for (int rt = 0; rt < RT; ++rt) for (int c = 0; c < 4; ++c) acc[rt][c] = 0.f;
     const float4 qconst = q[blockIdx.x & 1023];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j0 = 0; j0 < M; j0 += kTile) {
@@ -45,9 +46,9 @@ __global__ void __launch_bounds__(NW * 64) kern(const uint4* __restrict__ rec, c
         __syncthreads();
         for (int G = 0; G < kTile / 32; ++G) {
             const uint4 ya = tile[G * 128 + rec0], yb = tile[G * 128 + 64 + rec0];
-            f32x16 w[2];
+            f32x16 w[RT];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 f32x16 u = mfma(ya, X[rt][0], zero16);
                 u = mfma(yb, X[rt][1], u);
 #pragma unroll
@@ -62,13 +63,13 @@ __global__ void __launch_bounds__(NW * 64) kern(const uint4* __restrict__ rec, c
                         const float4 q4 = *reinterpret_cast<const float4*>(qg + c * kTile + qq * 8);
                         const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-                        for (int rt = 0; rt < 2; ++rt)
+                        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[rt][c] = __builtin_fmaf(w[rt][qq * 4 + r], qv[r], acc[rt][c]);
                     }
                 if (NQ == 3) {
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
                         float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int k = 0; k < 16; ++k) s4[k & 3] += w[rt][k];
@@ -112,21 +113,21 @@ __global__ void __launch_bounds__(NW * 64) kern(const uint4* __restrict__ rec, c
         }
     }
     float r = 0.f;
-    for (int rt = 0; rt < 2; ++rt) for (int c = 0; c < 4; ++c) r += acc[rt][c];
+    for (int rt = 0; rt < RT; ++rt) for (int c = 0; c < 4; ++c) r += acc[rt][c];
     out[(size_t)blockIdx.x * NW * 64 + tid] = r;
 }
 
-template <int VARIANT, int NQ, int NW>
+template <int VARIANT, int NQ, int NW, int RT = 2>
 void run(const char* name, const uint4* rec, const float4* q, float* out, int M, int wgs) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((kern<VARIANT, NQ, NW>), dim3(wgs), dim3(NW * 64), 0, 0, rec, q, out, M);
+        hipLaunchKernelGGL((kern<VARIANT, NQ, NW, RT>), dim3(wgs), dim3(NW * 64), 0, 0, rec, q, out, M);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double pairs = (double)wgs * NW * 64 * M;      // 64 rows per wavefront
+    const double pairs = (double)wgs * NW * 32 * RT * M;      // 32 RT rows per wavefront
     printf("  %-58s %8.3f ms   -> %7.1f ms per 1e12 pairs   (%.1f cycles per 64 pairs at 2.4 GHz)\n", name, ms, ms * 1e12 / pairs,
            ms * 1e-3 * 2.4e9 * 1024 / (pairs / 64));
 }
@@ -151,5 +152,9 @@ int main() {
     run<0, 3, 8>("q from LDS (float4 broadcast), soft-min gradient, 8 waves", rec, q, out, M, wgs / 2);
     run<1, 3, 8>("swap + SGPR q,                soft-min gradient, 8 waves", rec, q, out, M, wgs / 2);
     run<1, 4, 8>("swap + SGPR q,                gaussian gradient, 8 waves", rec, q, out, M, wgs / 2);
+    run<0, 3, 2, 4>("q from LDS, FOUR row tiles per wavefront, soft-min gradient, 2 waves", rec, q, out, M, wgs);
+    run<0, 4, 2, 4>("q from LDS, FOUR row tiles per wavefront, gaussian gradient, 2 waves", rec, q, out, M, wgs);
+    run<0, 3, 4, 4>("q from LDS, FOUR row tiles per wavefront, soft-min gradient, 4 waves", rec, q, out, M, wgs / 2);
+    run<0, 3, 4, 1>("q from LDS, ONE row tile per wavefront,   soft-min gradient, 4 waves", rec, q, out, M, wgs * 2);
     return 0;
 }
