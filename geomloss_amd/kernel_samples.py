@@ -17,7 +17,7 @@ import torch
 from . import hip
 from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, from_matrix, grid_cluster,
                       native_clustering_applies, sort_clusters)
-from .utils import distances, scal, squared_distances
+from .utils import distances, scal, scal_sum, squared_distances
 
 
 class DoubleGrad(torch.autograd.Function):
@@ -109,17 +109,26 @@ def _kernel_operators(x, y, blur, kernel, name, lazy, ranges):
     return build(double_grad(x), x.detach(), r_xx), build(double_grad(y), y.detach(), r_yy), build(x, y, r_xy)
 
 
-# Self-terms over the upper triangle.  <a, K_xx a> is a symmetric quadratic form: when nothing but the VALUE of the loss is wanted
-# (no gradient flows, no potentials) the pairs (i, j) and (j, i) need not both be evaluated.  The rows are cut into blocks of 256
-# (the row tile of the kernels); block I reduces once over its own columns (the diagonal block, both orientations inside it) and
-# once over the columns of the blocks after it, counted twice — two block-sparse launches of the ordinary product kernel, half the
-# pair evaluations of the dense product.  Kernel norms at N = M = 1e6, forward only: 3 reductions of 1e12 pairs become 2.
-# The three dot products <a, .> and their combination are carried in float64 there (1e6 terms each; the loss between two samples
-# of one law is 1e-6 of its terms, a dozen float32 quanta of the energy distance's).
-# Not used when a gradient is wanted, even for the self-term of a measure that takes none: the three products of a loss then run
-# in one kernel family so that their common rounding bias (gaussian: -1.6e-5 relative, from the float32 accumulation of
-# exponent terms of size diam^2 / blur^2) cancels in the difference; a term evaluated another way would carry another bias
-# (measured: profiles/r03_upper_triangle.txt).
+# The matrix-free dense path evaluates the norm on the UNION cloud.  With z = (x, y) and the signed weights w = (α, -β),
+#
+#     Loss = 1/2 <α-β, k*(α-β)> = 1/2 <w, K_zz w> = 1/2 ( <α, U_x> - <β, U_y> ),   U = K_zz w  (rows of x, rows of y)
+#
+# and U_x = k*α - k*β on x, -U_y = k*β - k*α on y are the potentials of ``:139-141``.  It is the same number as the reference's
+# three terms 1/2 <α, K_xx α> + 1/2 <β, K_yy β> - <α, K_xy β> (``:143-146``), but those are three LARGE terms: between two samples
+# of one law at 1e6 points the gaussian loss is 5e-4 of each of them, the energy distance 6e-7 — and every fast kernel here carries
+# a one-sided rounding bias of 1e-6 ... 1e-5 per kernel value (the float32 accumulation of the bf16x3 exponent inside the MFMA,
+# DESIGN §4.3c), which the three-term form only survives if the three launches happen to share it (round 3: 4e-4 off at 1e6
+# without gradients, 2.4e-4 between the gradient and the no-gradient answer of one input).  In the union form the positive and
+# negative columns of a row are summed by ONE launch, relative to ONE centre: whatever bias a kernel value carries multiplies
+# a difference, not a term, and the relative error of the loss is that of a kernel value.  The dot products are carried in
+# float64 (utils.scal on GPU tensors).  Pair evaluations: (N + M)^2 instead of N^2 + M^2 + N M; the value-only case below
+# halves that again.
+#
+# Value only (no gradient flows, no potentials), one big un-batched problem: <w, K_zz w> is a symmetric quadratic form, so the
+# pairs (i, j) and (j, i) need not both be evaluated.  The union cloud is put in compact order (hip.compact_order: x and y points
+# interleaved along a voxel path, every 256-row block compact), cut into blocks of 256 rows (the row tile of the kernels); block
+# I reduces once over its own columns (the diagonal block, both orientations inside it) and once over the columns of the blocks
+# after it, counted twice — two block-sparse launches of the ordinary product kernel, (N + M)^2 / 2 pair evaluations.
 _UPPER_BLOCK, _UPPER_CHUNKS, _UPPER_MIN_PAIRS = 256, 8, 2e9
 _UPPER_KERNELS = ("gaussian", "laplacian", "energy")
 
@@ -143,30 +152,50 @@ def _upper_triangle_patterns(N, device):
     return diag, upper
 
 
-def _self_term_value(name, x, w, blur):
-    """<w, K_xx w> for one un-batched cloud x (1,N,D)|(N,D) from the upper triangle, no autograd graph; a 0-dim float64 tensor.
-    laplacian / energy: the cloud is first put in the compact order of hip.compact_order, so that the 256-row blocks are what the
-    matrix-core distance kernels want (hip._KernelConv switches them on for block-sparse launches)."""
-    xd = x.detach().reshape(-1, x.shape[-1])
+def _quadratic_form_value(name, z, w, blur):
+    """<w, K_zz w> for one un-batched cloud z (1,N,D)|(N,D) with (signed) weights w, from the upper triangle; no autograd graph;
+    a 0-dim float64 tensor.  The cloud is first put in the compact order of hip.compact_order: the 256-row blocks are then what
+    the matrix-core distance kernels want (hip._KernelConv switches them on for block-sparse launches), and the points of the two
+    measures of a norm are interleaved in every row block and every column tile."""
+    zd = z.detach().reshape(-1, z.shape[-1])
     wv = w.detach().reshape(-1).float()
-    if name != "gaussian":
-        perm, xd = hip.compact_order(xd)
-        wv = wv[perm]
-    N = xd.shape[0]
-    diag, upper = _upper_triangle_patterns(N, xd.device)
-    d = hip.kernel_conv(name, xd, xd, wv, blur, ranges=diag)
-    u = hip.kernel_conv(name, xd, xd, wv, blur, ranges=upper)
+    perm, zd = hip.compact_order(zd)
+    wv = wv[perm]
+    diag, upper = _upper_triangle_patterns(zd.shape[0], zd.device)
+    d = hip.kernel_conv(name, zd, zd, wv, blur, ranges=diag)
+    u = hip.kernel_conv(name, zd, zd, wv, blur, ranges=upper)
     return torch.dot(wv.double(), d.double() + 2.0 * u.double())
 
 
-def _takes_no_gradient(w, pts):
-    return not (torch.is_grad_enabled() and (w.requires_grad or pts.requires_grad))
+def _takes_no_gradient(*tensors):
+    return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
 
 
-def _upper_triangle_applies(name, w, pts):
+def _upper_triangle_applies(name, pts):
     """One un-batched cloud of dimension <= 3, big enough for the two block-sparse launches to pay."""
     return (name in _UPPER_KERNELS and pts.shape[-1] <= 3 and float(pts.shape[-2]) ** 2 >= _UPPER_MIN_PAIRS
             and (pts.dim() == 2 or pts.shape[0] == 1))
+
+
+def _kernel_loss_union(α, x, β, y, blur, name, potentials):
+    """The matrix-free dense kernel norm (or its potentials) on the union cloud: see the note above."""
+    if name not in kernel_routines:
+        raise KeyError(name)
+    batch = x.dim() > 2
+    z = torch.cat((x.detach(), y.detach().to(x.dtype)), dim=-2)
+    w = torch.cat((α.detach().float(), -β.detach().float()), dim=-1)
+
+    if not potentials and _takes_no_gradient(α, x, β, y) and _upper_triangle_applies(name, z):
+        out = (0.5 * _quadratic_form_value(name, z, w, blur)).float()
+        return out.view(1) if batch else out
+
+    # rows of x, rows of y: each differentiates through its own rows only, with a doubled gradient (the quadratic form is
+    # symmetric: ``:117-125`` plays the same trick on K_xx and K_yy); the columns and their weights are constants
+    U_x = hip.kernel_conv(name, double_grad(x), z, w, blur)      # (k*α - k*β)(x_i)
+    U_y = hip.kernel_conv(name, double_grad(y), z, w, blur)      # (k*α - k*β)(y_j)
+    if potentials:
+        return U_x, -U_y
+    return 0.5 * scal_sum(double_grad(α), U_x, double_grad(β), -U_y, batch=batch)
 
 
 def kernel_loss(
@@ -176,22 +205,8 @@ def kernel_loss(
     """Kernel norm 1/2 <α-β, k*(α-β)> or its potentials (``:92-146``).  ``use_keops=True`` selects the matrix-free
     HIP path (the keyword keeps the reference's name; no KeOps is involved)."""
     batch = x.dim() > 2
-    if (use_keops and not potentials and kernel is None and ranges_xx is None and ranges_yy is None and ranges_xy is None
-            and _takes_no_gradient(α, x) and _takes_no_gradient(β, y)
-            and (_upper_triangle_applies(name, α, x) or _upper_triangle_applies(name, β, y)) and (not batch or x.shape[0] == 1)):
-        # value only, dense kernel norm with a big cloud: its symmetric self-term over the upper triangle (a small one: the full product)
-        def product(u, v, w):       # <a, K_uv w> in float64
-            k = hip.kernel_conv(name, u.detach(), v.detach(), w.detach().reshape(v.shape[:-1]), blur)
-            return k.reshape(-1).double()
-
-        def self_term(pts, w):
-            if _upper_triangle_applies(name, w, pts):
-                return _self_term_value(name, pts, w, blur)
-            return torch.dot(w.detach().reshape(-1).double(), product(pts, pts, w))
-
-        cross = torch.dot(α.detach().reshape(-1).double(), product(x, y, β))
-        out = (0.5 * (self_term(x, α) + self_term(y, β)) - cross).float()
-        return out.view(1) if batch else out
+    if use_keops and kernel is None and ranges_xx is None and ranges_yy is None and ranges_xy is None:
+        return _kernel_loss_union(α, x, β, y, blur, name, potentials)
 
     K_xx, K_yy, K_xy = _kernel_operators(x, y, blur, kernel, name, use_keops, (ranges_xx, ranges_yy, ranges_xy))
 

@@ -187,8 +187,9 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
 
 
 def _averaged(eps, lam, rows, cols, log_w, pot, prev):
-    """(prev + lam * softmin(eps, C, log_w + pot/eps)) / 2 as one fused launch (D <= 16) or soft-min + torch arithmetic."""
-    if rows.shape[1] <= hip.XD_MAX_DIM:
+    """(prev + lam * softmin(eps, C, log_w + pot/eps)) / 2 as one fused launch (D <= 16 on the default kernels) or soft-min +
+    torch arithmetic."""
+    if hip.fused_step_applies(rows.shape[1], 2):
         return hip.sinkhorn_step(eps, rows, cols, log_w, pot, prev, lam)
     return 0.5 * (prev + lam * hip.softmin(eps, rows, cols, log_w + pot / eps))
 

@@ -139,7 +139,7 @@ class _HipSoftmin:
     def step(self, eps, C, log_w, pot, damping, prev):
         x, y = C[0], C[1]
         ranges = C[4] if self.multiscale else None
-        if x.shape[-1] > (hip.XD_MAX_DIM if self.p == 2 else 3):  # no fused kernel on the generic-dimension path
+        if not hip.fused_step_applies(x.shape[-1], self.p):  # no fused kernel on the generic-dimension path (incl. D > 3 under NO_MFMA / DIRECT)
             ft = damping * self(eps, C, log_w if pot is None else log_w + pot / eps)
             return ft if prev is None else 0.5 * (prev + ft)
         flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)

@@ -371,6 +371,32 @@ def test_cfg5_gaussian_mmd_1e6_loss_and_gradient(cuda):
     assert e[0] < 1e-4 and e[1] < 1e-4
 
 
+@pytest.mark.parametrize("name", ["gaussian", "energy", "laplacian"])
+def test_kernel_norms_1e6_same_law_with_and_without_gradients(cuda, name):
+    """The three kernel norms at N = M = 1e6 on the clouds bench.py times them on (seed 1: two samples of one law, so the loss is
+    5e-4 (gaussian) ... 6e-7 (energy) of the three terms the reference sums), against the float64 oracle: the value-only path
+    (`torch.no_grad()`: what `gaussian_online_1e6_fwd` times), the path that also returns a gradient, and the two against each
+    other — one input, one answer.  Bar: 1e-4 relative ON THE LOSS, no term-sized slack (round-3 review: 4.1e-4 / 3.9e-4 value-only,
+    2.4e-4 between the two modes, 17 % for the energy distance under gradients)."""
+    N = 1_000_000
+    x, y = _uniform_clouds(1, N, N, cuda)
+    loss = SamplesLoss(name, blur=0.05, backend="online")
+    with torch.no_grad():
+        L0 = loss(x, y).item()
+    xg = x.clone().requires_grad_(True)
+    L1t = loss(xg, y)
+    (gx,) = torch.autograd.grad(L1t, [xg])
+    L1, gx = L1t.item(), gx.cpu().numpy()
+    del L1t
+    torch.cuda.empty_cache()
+    ref, rgx, _ = o64.kernel_loss(name, x, y, blur=0.05, grad=True, device=cuda, budget=1 << 28)
+    e0, e1, e01, eg = abs(L0 - ref) / abs(ref), abs(L1 - ref) / abs(ref), abs(L0 - L1) / abs(ref), relerr(gx, rgx)
+    print(f"{name} 1e6 same law: oracle {ref:.9e}; value only {L0:.9e} rel {e0:.2e}; with gradient {L1:.9e} rel {e1:.2e}; "
+          f"between the two {e01:.2e}; dL/dx rel {eg:.2e}")
+    assert e0 < 1e-4 and e1 < 1e-4 and e01 < 1e-4
+    assert eg < 1e-4
+
+
 def G_fine(gen, M, dev):
     """A smooth-ish dual potential of realistic size (|g| <~ diam^2 / 2) plus noise."""
     return (0.05 * torch.randn(M, generator=gen)).to(dev)

@@ -236,10 +236,12 @@ def test_from_matrix_covers_exactly_the_kept_pairs_in_both_orientations():
     assert rg.redranges_j.shape[0] == n_runs
 
 
-def test_kernel_norm_sends_its_three_products_to_one_arithmetic(monkeypatch):
-    """A kernel norm is a difference of three large terms: when gradients are on, the two products that run the one-pass
-    product-and-gradient kernel and the third one must share their rounding (GLHIP_FLAG_GRAD_FAMILY); gradient-free calls
-    keep the default kernels.  Host logic only: the launches are recorded, not run."""
+def test_kernel_norm_runs_on_the_union_cloud(monkeypatch):
+    """The matrix-free dense kernel norm is 1/2 <w, K_zz w> on the union cloud z = (x, y) with signed weights w = (a, -b): two
+    launches (rows of x, rows of y) whose columns are ALL the points, so that the positive and the negative columns of a row are
+    summed by one launch around one centre (kernel_samples._kernel_loss_union); default kernel family whatever the gradients.
+    The block-sparse (multiscale) norm keeps the three products of the reference, in one family when gradients are on
+    (GLHIP_FLAG_GRAD_FAMILY).  Host logic only: the launches are recorded, not run."""
     from geomloss_amd import kernel_samples as ks
 
     header = open(os.path.join(ROOT, "include", "glhip.h")).read()
@@ -247,7 +249,7 @@ def test_kernel_norm_sends_its_three_products_to_one_arithmetic(monkeypatch):
     seen = []
 
     def record(kind, x, y, v, blur=0.05, ranges=None, flags=0):
-        seen.append((kind, int(flags), x.requires_grad))
+        seen.append((kind, int(flags), x.requires_grad, tuple(x.shape), tuple(y.shape), v.detach().clone()))
         return (v.sum(-1, keepdim=True) + 0 * x.sum(-1)).expand(x.shape[:-1]) if v.dim() == x.dim() - 1 else v
 
     monkeypatch.setattr(hip, "kernel_conv", record)
@@ -257,15 +259,23 @@ def test_kernel_norm_sends_its_three_products_to_one_arithmetic(monkeypatch):
         for grad in (False, True):
             seen.clear()
             ks.kernel_online(a, x.clone().requires_grad_(grad), b, y, blur=0.1, name=name)
-            assert len(seen) == 3
-            assert {f for _, f, _ in seen} == ({hip.FLAG_GRAD_FAMILY} if grad else {0}), (name, grad, seen)
+            assert [(s[3], s[4]) for s in seen] == [((7, 3), (12, 3)), ((5, 3), (12, 3))] and {s[1] for s in seen} == {0}
+            assert [s[2] for s in seen] == [grad, False]
+            for s in seen:
+                assert torch.equal(s[5], torch.cat((a, -b)))
+    seen.clear()                  # batches: the union along the point axis
+    ks.kernel_online(a.expand(2, -1), x.expand(2, -1, -1), b.expand(2, -1), y.expand(2, -1, -1), blur=0.1, name="gaussian")
+    assert [(s[3], s[4]) for s in seen] == [((2, 7, 3), (2, 12, 3)), ((2, 5, 3), (2, 12, 3))]
+    # block-sparse norm: three products, one family under gradients
+    R = object()
+    for grad, want in ((False, {0}), (True, {hip.FLAG_GRAD_FAMILY})):
         seen.clear()
-        with torch.no_grad():     # inference on leaves that require gradients: default kernels
-            ks.kernel_online(a, x.clone().requires_grad_(True), b, y, blur=0.1, name=name)
-        assert {f for _, f, _ in seen} == {0}
-    seen.clear()                  # D > 3: the generic kernels have no one-pass mode
-    ks.kernel_online(a, torch.rand(7, 5).requires_grad_(True), b, torch.rand(5, 5), blur=0.1, name="gaussian")
-    assert {f for _, f, _ in seen} == {0}
+        ks.kernel_loss(a, x.clone().requires_grad_(grad), b, y, blur=0.1, name="gaussian", use_keops=True, ranges_xx=R, ranges_yy=R, ranges_xy=R)
+        assert len(seen) == 3 and {s[1] for s in seen} == want
+    seen.clear()
+    with torch.no_grad():     # inference on leaves that require gradients: default kernels
+        ks.kernel_loss(a, x.clone().requires_grad_(True), b, y, blur=0.1, name="gaussian", use_keops=True, ranges_xx=R, ranges_yy=R, ranges_xy=R)
+    assert {s[1] for s in seen} == {0}
 
 
 def test_upper_triangle_patterns_cover_each_unordered_block_pair_once():
@@ -290,49 +300,97 @@ def test_upper_triangle_patterns_cover_each_unordered_block_pair_once():
 
 
 def test_kernel_norm_value_only_launches(monkeypatch):
-    """No gradient anywhere + big clouds: cross product + (diagonal, upper) launches per self-term, default kernel family, float64
-    combination; any gradient, potentials, batches, user ranges or small clouds: the three full products.  Launches recorded, not run."""
+    """No gradient anywhere + a big problem: the quadratic form <w, K_zz w> over the upper triangle of the union cloud in compact
+    order — (diagonal, upper) block-sparse launches, float64 combination; any gradient, potentials, batches or small clouds: the
+    two row passes; user ranges: the three products of the reference.  Launches recorded, not run."""
     from geomloss_amd import kernel_samples as ks
 
     seen = []
 
     def record(kind, x, y, v, blur=0.05, ranges=None, flags=0):
-        seen.append((kind, ranges is not None, int(flags)))
-        return torch.ones(x.shape[:-1], dtype=torch.float32) * v.sum() + 0 * x.sum(-1)
+        seen.append((kind, ranges is not None, int(flags), x.shape[-2], y.shape[-2]))
+        return torch.ones(x.shape[:-1], dtype=torch.float32) * v.abs().sum() + 0 * x.sum(-1)
 
+    sorted_clouds = []
     monkeypatch.setattr(hip, "kernel_conv", record)
-    monkeypatch.setattr(hip, "compact_order", lambda pts: (torch.arange(pts.shape[0]), pts))
+    monkeypatch.setattr(hip, "compact_order", lambda pts: (sorted_clouds.append(pts.shape[0]), (torch.arange(pts.shape[0]), pts))[1])
     monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 0.0)
     x, y = torch.rand(300, 3), torch.rand(280, 3)
     a, b = torch.full((300,), 1 / 300), torch.full((280,), 1 / 280)
     for name in ("gaussian", "laplacian", "energy"):
         seen.clear()
+        sorted_clouds.clear()
         L = ks.kernel_online(a, x, b, y, blur=0.1, name=name)
-        assert [r for _, r, _ in seen] == [False, True, True, True, True] and {f for _, _, f in seen} == {0}
-        assert L.dtype == torch.float32 and L.shape == () and abs(L.item() - 2.0) < 1e-5    # 1/2 (3 + 3) - 1: every stand-in product is 1, a . (d + 2 u) = 3
+        assert [s[1:] for s in seen] == [(True, 0, 580, 580)] * 2 and sorted_clouds == [580]
+        # every stand-in product is |w|_1 = 2, w . (d + 2 u) = (1 - 1) * 6 = 0
+        assert L.dtype == torch.float32 and L.shape == () and abs(L.item()) < 1e-6
         assert ks.kernel_online(a[None], x[None], b[None], y[None], blur=0.1, name=name).shape == (1,)
-        for kw in (dict(potentials=True), dict(ranges_xy=object())):
-            seen.clear()
-            try:
-                ks.kernel_online(a, x, b, y, blur=0.1, name=name, **kw)
-            except Exception:
-                pass
-            assert seen and not any(r and kw.get("potentials") for _, r, _ in seen) and len(seen) <= 4
+        seen.clear()
+        F, G = ks.kernel_online(a, x, b, y, blur=0.1, name=name, potentials=True)
+        assert [s[1:] for s in seen] == [(False, 0, 300, 580), (False, 0, 280, 580)] and F.shape == (300,) and G.shape == (280,)
+        seen.clear()
+        try:
+            ks.kernel_online(a, x, b, y, blur=0.1, name=name, ranges_xy=object())
+        except Exception:
+            pass
+        assert [s[3:] for s in seen[:1]] == [(300, 300)]                    # the reference's three products: K_xx first
         for args in ((a, x.clone().requires_grad_(True), b, y), (a, x, b.clone().requires_grad_(True), y)):
             seen.clear()
-            ks.kernel_online(*args, blur=0.1, name=name)
-            assert len(seen) == 3 and not any(r for _, r, _ in seen)
+            out = ks.kernel_online(*args, blur=0.1, name=name)
+            assert [s[1:] for s in seen] == [(False, 0, 300, 580), (False, 0, 280, 580)] and out.requires_grad
         seen.clear()
         ks.kernel_online(a.expand(2, -1), x.expand(2, -1, -1), b.expand(2, -1), y.expand(2, -1, -1), blur=0.1, name=name)
-        assert len(seen) == 3
-    monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 300.0 ** 2)     # x (300 points) is "big", y (280) is not: one upper triangle, one full product
-    seen.clear()
-    L = ks.kernel_online(a, x, b, y, blur=0.1, name="gaussian")
-    assert [r for _, r, _ in seen] == [False, True, True, False] and abs(L.item() - 1.0) < 1e-5        # 1/2 (3 + 1) - 1
+        assert len(seen) == 2 and not any(s[1] for s in seen)
     monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 2e9)
     seen.clear()
     ks.kernel_online(a, x, b, y, blur=0.1, name="gaussian")
-    assert len(seen) == 3 and not any(r for _, r, _ in seen)
+    assert len(seen) == 2 and not any(s[1] for s in seen)
+
+
+def test_loss_formulas_sum_in_float64_on_the_gpu_only():
+    """utils.scal / scal_sum: the reference's float32 expressions on CPU tensors (the tensorized backend is bit-identical to the
+    reference there), float64 accumulation behind the `is_cuda` test."""
+    from geomloss_amd import utils
+    g = torch.Generator().manual_seed(0)
+    a, f, b, h = (torch.rand(1000, generator=g) for _ in range(4))
+    assert torch.equal(utils.scal(a, f), torch.dot(a, f))
+    assert torch.equal(utils.scal_sum(a, f, b, h), torch.dot(a, f) + torch.dot(b, h))
+    A, F = a.view(4, 250), f.view(4, 250)
+    assert torch.equal(utils.scal(A, F, batch=True), (A * F).sum(1))
+    assert not utils._widen(a, f) and not utils._widen(a.double(), f)
+
+
+def test_fused_half_step_dispatch_follows_the_flags(monkeypatch):
+    """hip.fused_step_applies: glhip_sinkhorn_step has a kernel for D <= 3 whatever the flags, for 4 <= D <= 16 only on the default
+    p = 2 matrix-core kernel — under GEOMLOSS_HIP_FLAGS = NO_MFMA / DIRECT (README knobs) those dimensions must take the unfused
+    composition (round-3 regression: they raised NotImplementedError).  The Sinkhorn drivers ask this function."""
+    for env in (0, hip.FLAG_NO_SPLIT, hip.FLAG_XDL16):
+        monkeypatch.setattr(hip, "ENV_FLAGS", env)
+        assert all(hip.fused_step_applies(D, p) for D in (1, 2, 3) for p in (1, 2))
+        assert all(hip.fused_step_applies(D, 2) for D in (4, 5, 8, 16)) and not hip.fused_step_applies(17, 2)
+        assert not any(hip.fused_step_applies(D, 1) for D in (4, 8, 16, 17))
+    for env in (hip.FLAG_NO_MFMA, hip.FLAG_DIRECT, hip.FLAG_NO_MFMA | hip.FLAG_DIRECT):
+        monkeypatch.setattr(hip, "ENV_FLAGS", env)
+        assert all(hip.fused_step_applies(D, p) for D in (1, 2, 3) for p in (1, 2))
+        assert not any(hip.fused_step_applies(D, p) for D in (4, 5, 8, 16, 17) for p in (1, 2))
+    monkeypatch.setattr(hip, "ENV_FLAGS", 0)
+    assert not hip.fused_step_applies(5, 2, flags=hip.FLAG_NO_MFMA) and hip.fused_step_applies(3, 2, flags=hip.FLAG_NO_MFMA)
+
+    # the drivers: _HipSoftmin.step and ot._averaged compose soft-min + arithmetic instead of calling the fused entry point
+    from geomloss_amd import sinkhorn_samples as ss
+    from geomloss_amd.ot import sinkhorn_ot
+    calls = []
+    monkeypatch.setattr(hip, "sinkhorn_step", lambda *a, **k: (calls.append("step"), torch.zeros(7))[1])
+    monkeypatch.setattr(hip, "softmin", lambda eps, x, y, h, **k: (calls.append("softmin"), torch.zeros(x.shape[0]))[1])
+    x, y, lw = torch.rand(7, 5), torch.rand(6, 5), torch.zeros(6)
+    for env, want in ((0, ["step"]), (hip.FLAG_NO_MFMA, ["softmin"]), (hip.FLAG_DIRECT, ["softmin"])):
+        monkeypatch.setattr(hip, "ENV_FLAGS", env)
+        calls.clear()
+        ss._HipSoftmin(2, multiscale=False).step(0.1, (x, y), lw.view(1, -1), lw.view(1, -1), 1.0, torch.zeros(1, 7))
+        assert calls == want, (env, calls)
+        calls.clear()
+        sinkhorn_ot._averaged(0.1, 1.0, x, y, lw, lw, torch.zeros(7))
+        assert calls == want, (env, calls)
 
 
 # ---- C-ABI ------------------------------------------------------------------------------------------

@@ -1,18 +1,46 @@
 #!/bin/bash
 # GPU box: the measurement artefacts of a round in one call (~10 GPU-minutes).  usage: bash tools/final_measure.sh <tag>
 # Copy what should be judged from gpurun_out/ into profiles/ afterwards.
+# Every leg's exit status is checked: a leg that fails (a traceback, a timeout) is named on stdout and in
+# gpurun_out/final_measure_<tag>.status, its output file is renamed *.FAILED so that it cannot be mistaken for a report,
+# and the script exits non-zero.
 set -u
 TAG=${1:-r02}
 mkdir -p gpurun_out
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
-bash tools/profile_gpu.sh $TAG > /dev/null 2>&1                       # kernel trace + PMC passes of the headline command
-python tools/summarize_profile.py gpurun_out/prof_$TAG $TAG > /dev/null 2>&1
-bash tools/profile_kernels.sh $TAG > /dev/null 2>&1                   # kernel trace + PMC of every reduction at 1e6
-bash tools/trace_all.sh > /dev/null 2>&1                              # per-config kernel traces
-timeout 300 python tools/accuracy_report.py > gpurun_out/accuracy_report.txt 2>&1
-timeout 200 python tools/fuzz_kernels.py 600 3 > gpurun_out/fuzz.txt 2>&1
-timeout 200 python tools/small_probe.py > gpurun_out/small_probe.txt 2>&1
-timeout 100 python tools/probe_batch.py > gpurun_out/probe_batch.txt 2>&1
-timeout 100 python tools/first_call.py > gpurun_out/first_call.txt 2>&1
-timeout 500 python tools/reference_protocol_bench.py --quick > gpurun_out/reference_protocol.log 2>&1
-tail -c 400 gpurun_out/bench_$TAG.json
+STATUS=gpurun_out/final_measure_$TAG.status
+: > $STATUS
+FAIL=0
+
+leg() {   # leg <name> <output file | -> <timeout s> <command...>
+    local name=$1 out=$2 limit=$3
+    shift 3
+    if [ "$out" = "-" ]; then
+        timeout "$limit" "$@" > /dev/null 2> gpurun_out/$name.err
+    else
+        timeout "$limit" "$@" > "$out" 2> gpurun_out/$name.err
+    fi
+    local rc=$?
+    if [ $rc -ne 0 ]; then
+        echo "FAILED leg '$name' (exit $rc): $*" | tee -a $STATUS
+        tail -n 5 gpurun_out/$name.err | sed 's/^/    /' | tee -a $STATUS
+        [ "$out" != "-" ] && [ -e "$out" ] && mv "$out" "$out.FAILED"
+        FAIL=1
+    else
+        echo "ok     leg '$name'" >> $STATUS
+    fi
+}
+
+leg bench gpurun_out/bench_$TAG.json 900 python bench.py --steps 20 --warmup 5
+leg profile_gpu - 900 bash tools/profile_gpu.sh $TAG                    # kernel trace + PMC passes of the headline command
+leg summarize_profile - 200 python tools/summarize_profile.py gpurun_out/prof_$TAG $TAG
+leg profile_kernels - 900 bash tools/profile_kernels.sh $TAG            # kernel trace + PMC of every reduction at 1e6
+leg trace_all - 900 bash tools/trace_all.sh                             # per-config kernel traces
+leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_report.py
+leg fuzz gpurun_out/fuzz.txt 200 python tools/fuzz_kernels.py 600 3
+leg small_probe gpurun_out/small_probe.txt 200 python tools/small_probe.py
+leg probe_batch gpurun_out/probe_batch.txt 100 python tools/probe_batch.py
+leg first_call gpurun_out/first_call.txt 100 python tools/first_call.py
+leg reference_protocol gpurun_out/reference_protocol.log 500 python tools/reference_protocol_bench.py --quick
+cat $STATUS
+[ -e gpurun_out/bench_$TAG.json ] && tail -c 400 gpurun_out/bench_$TAG.json
+exit $FAIL
