@@ -29,6 +29,8 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
             ng = ng > nx ? ng : nx;
         }
         const size_t grad = (size_t)(ng < 2 ? 0 : ng) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
+        if (n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8)    // forward, big dense launches: + the pre-packed column records
+            bytes += 256 + (size_t)B * (size_t)((M + 31) / 32) * 32 * (size_t)(2 * ((D + 2) / 2)) * sizeof(uint4);
         bytes = bytes > grad ? bytes : grad;
         if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);
         return bytes;

@@ -362,6 +362,7 @@ constexpr long kXdSlots = 256 * 2;    // resident 8-wave workgroups (<= 48 KiB o
 template <int MODE, int D, typename T, class MergeOp, int RT, int NW>
 void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                    int M, const Scratch& sc, hipStream_t st) {
+    using S = XdShape<D>;
     constexpr int kPart = MODE == XD_SOFTMIN ? 2 : 1;
     static_assert(MergeOp::kPartial == kPart, "partial formats differ");
     static_assert(MergeOp::kRows == 1, "the merge launch below tiles rows in blocks of kBlock");
@@ -379,24 +380,39 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
     sp.xcd_blocks = 0;
     const int gx = (N + kRows - 1) / kRows;
     const dim3 merge_grid((N + kBlock - 1) / kBlock, B, 1);
+    const XdPacked none{nullptr, 0};
     if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD at a time (workgroup_coords)
-        const int nx = xcd_splits((long)gx * B, M, kXdSlots, fit);
+        // pre-packed columns (glhip_softmin_xd.h): the records of all columns once, in workspace behind the split partials
+        XdPacked pk{nullptr, (long)((M + 31) / 32) * S::kGroupRecs};
+        const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
+        static const bool allow_pre = []() { const char* e = getenv("GLHIP_XD_PRE"); return !e || atoi(e) != 0; }();   // A/B knob
+        const long fit_pre = (sc.ws && sc.bytes > packed_bytes + 256) ? (long)((sc.bytes - packed_bytes - 256) / per_split) : 0;
+        const bool pre = NW == 8 && allow_pre && sc.prepack((double)B * N * M) && fit_pre >= 8;
+        const int nx = pre ? xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0) : xcd_splits((long)gx * B, M, kXdSlots, fit);
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
             sp.n_splits = nx;
             sp.xcd_grid_x = gx;
             sp.xcd_blocks = gx * B;
-            hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            const size_t part_bytes = (((size_t)nx * per_split) + 255) & ~(size_t)255;
+            if (pre) {
+                pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+                hipLaunchKernelGGL((xd_pack_kernel<MODE, D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+                if constexpr (NW == 8)
+                    hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+            } else {
+                hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
+            }
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
         }
     }
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, true, RT, NW>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, true, RT, NW, false>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, none);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
-        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
     }

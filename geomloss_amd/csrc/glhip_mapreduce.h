@@ -251,9 +251,9 @@ static inline int xcd_splits(long row_blocks, int M, long slots, long max_by_wor
 
 // ... and when the columns are pre-packed (64 bytes each), enough splits for one split's records to stay resident in the
 // 4 MB L2 of the XCD that streams them (workgroup_coords runs one split per XCD at a time).
-static inline int xcd_splits_prepacked(long row_blocks, int M, long slots, long max_by_workspace) {
+static inline int xcd_splits_prepacked(long row_blocks, int M, long slots, long max_by_workspace, double bytes_per_column = 64.0) {
     int ns = xcd_splits(row_blocks, M, slots, max_by_workspace);
-    while (ns + 8 <= 32 && ns + 8 <= max_by_workspace && (double)M / ns * 64.0 > 2.5e6) ns += 8;
+    while (ns + 8 <= 32 && ns + 8 <= max_by_workspace && (double)M / ns * bytes_per_column > 2.5e6) ns += 8;
     return ns;
 }
 

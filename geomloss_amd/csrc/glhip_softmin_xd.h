@@ -15,9 +15,15 @@
 // one-thread-per-row VALU kernel of glhip_generic.h (2 instructions per pair and dimension), which stays for D > 16, p = 1 and
 // the gradients.
 //
-// LDS: NBP = 2 NM records of 16 bytes per column (the last one is a zero pad when D + 1 is odd), tiles of 512 / 256 / 128 columns
-// (<= 48 KiB).  Columns are split into pieces when a tile is staged (no pre-packed copy: the pieces of one column serve RT x NW x 32
-// = 512 rows of the workgroup's pass on big launches, which amortises the ~13 VALU instructions per coordinate).
+// LDS: NBP = 2 NM records of 16 bytes per column (the last one is a zero pad when D + 1 is odd).
+//   * on-the-fly staging (small and block-sparse launches): tiles of 512 / 256 / 128 columns (<= 48 KiB); every workgroup splits
+//     the columns of a tile into bf16 pieces itself (~13 VALU instructions per coordinate and column, shared by the RT x NW x 32
+//     rows of its pass: 11 % of the VALU work of a pass at D = 8 with 512 rows, 43 % at D = 16 with 256);
+//   * pre-packed columns (PRE, big dense launches; round 4): `xd_pack_kernel` writes the records of all columns ONCE, in the LDS
+//     tile order, and the reducing workgroups copy whole tiles with LDS-DMA (`global_load_lds_dwordx4`: 1 KiB per wavefront
+//     instruction, no staging registers, no VALU) into one of TWO tile buffers while the other one is being consumed: one
+//     barrier per tile instead of two, and the matrix / VALU pipes never wait for the packing.  One centre per launch
+//     (launch_centre), as for the D <= 3 kernel.
 #pragma once
 
 #include "glhip_softmin_x32.h"
@@ -32,7 +38,11 @@ struct XdShape {
     static constexpr int NB = D + 1;                 // K blocks in use: D coordinates + the scalar block
     static constexpr int NM = (NB + 1) / 2;          // chained MFMAs per 32 x 32 block
     static constexpr int NBP = 2 * NM;               // records per column in LDS
-    static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);   // columns per LDS tile
+    static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);   // columns per LDS tile (on-the-fly staging)
+    // pre-packed columns: two tile buffers of at most 2304 records (36 KiB) each — two 8-wave workgroups per CU hold 144 of the
+    // 160 KiB — in whole groups of 32 columns: 384 columns at D = 4, 5 ... 128 at D = 14 .. 16
+    static constexpr int kTilePre = (2304 / NBP) / 32 * 32;
+    static constexpr int kGroupRecs = 32 * NBP;      // records of one column group = NM chunks of 64 records (1 KiB)
     static constexpr int HM = D / 2;                 // the scalar block is K block D: MFMA D / 2 ...
     static constexpr int HH = D % 2;                 // ... lane half D % 2
 };
@@ -71,6 +81,36 @@ __device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long
     if (MODE == XD_GAUSS) *vdst = vj;
 }
 
+// Packed records of a whole launch: [B][ceil(M / 32)][NBP K blocks][32 columns] — the LDS tile layout, so that a tile (which
+// starts on a group boundary) is a contiguous run.  Columns j >= M of the last group are neutral (H = -big, zero coordinates).
+struct XdPacked {
+    uint4* rec;
+    long stride;    // records per batch item = ceil(M / 32) * 32 * NBP
+};
+
+template <int MODE, int D, typename T>
+__global__ void __launch_bounds__(kBlock)
+xd_pack_kernel(SoftminParams<T> prm, int N, int M, XdPacked pk) {
+    using S = XdShape<D>;
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= ((M + 31) & ~31)) return;
+    float centre[D];
+    launch_centre<D, T>(prm.x, b, N, centre);
+    float unused;
+    pack_column_xd<MODE, D, T>(prm, (long)b * M + j, j < M, centre,
+                                                                      pk.rec + b * pk.stride + (long)(j >> 5) * S::kGroupRecs + (j & 31), 32, &unused);
+}
+
+// LDS-DMA: lane l of the wavefront copies 16 (4) bytes from its own global address to lds_base + 16 l (4 l); lds_base must be
+// wave-uniform.  Completion is tracked by vmcnt of the issuing wavefront; readers need that wait followed by a barrier.
+__device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+
 // the chained MFMAs of one 32 x 32 block: column group `g` (LDS) against the x-side operands X
 template <int NM, int NBP>
 __device__ __forceinline__ f32x16 xd_block(const uint4* __restrict__ g, int rec0, const uint4 (&X)[NM], const f32x16& zero16) {
@@ -94,16 +134,19 @@ __device__ __forceinline__ float xd_weighted_sum(const f32x16& u, const float* _
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <int MODE, int D, typename T, bool SPARSE, int RT, int NW>
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
 __global__ void __launch_bounds__(NW * 64)
-xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPacked pk) {
     using S = XdShape<D>;
-    constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
+    static_assert(!(PRE && SPARSE), "pre-packed columns serve dense launches");
+    constexpr int NM = S::NM, NBP = S::NBP, kTileD = PRE ? S::kTilePre : S::kTile;
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
-    __shared__ uint4 tile[kTileD * NBP];                      // [column group of 32][K block 0..NBP-1][column]
-    __shared__ __attribute__((aligned(16))) float tileV[MODE == XD_GAUSS ? kTileD : 4];    // gaussian: the weights v_j of the tile (read back as float4)
+    constexpr int kBufs = PRE ? 2 : 1;
+    __shared__ uint4 tileBuf[kBufs * kTileD * NBP];           // [buffer][column group of 32][K block 0..NBP-1][column]
+    constexpr int kTileV = (kTileD + 63) & ~63;               // weights travel 64 at a time (one 4-byte LDS-DMA instruction)
+    __shared__ __attribute__((aligned(16))) float tileVBuf[MODE == XD_GAUSS ? kBufs * kTileV : 4];    // gaussian: the weights v_j of the tile (read back as float4)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,7 +168,8 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
-        load_point<D, T>(prm.x, (long)b * N + row0, centre);
+        if (PRE) launch_centre<D, T>(prm.x, b, N, centre);
+        else load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
         const int wave_row0 = row0 + wave * kRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
@@ -162,17 +206,49 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         }
         bool first_group = (MODE == XD_SOFTMIN);
 
+        // PRE: tile t + 1 of the split travels into the other buffer (LDS-DMA, issued right after the barrier that ends tile t - 1)
+        // while tile t is consumed.  The split's columns are whole groups of 32, like the packed layout.
+        int pre_js = 0, pre_je = 0;
+        if (PRE) {
+            const int len = (((M + ns - 1) / ns) + 31) & ~31;
+            pre_js = min(M, split * len);
+            pre_je = min(M, pre_js + len);
+        }
+        auto stage = [&](int j0, int buf) {
+            const int nGs = (min(kTileD, pre_je - j0) + 31) >> 5;
+            const uint4* src = pk.rec + b * pk.stride + (long)(j0 >> 5) * S::kGroupRecs;
+            for (int c = wave; c < nGs * NM; c += NW) glds16(src + c * 64 + lane, &tileBuf[buf * (kTileD * NBP) + c * 64]);
+            if (MODE == XD_GAUSS) {      // 64 weights per wavefront instruction; columns past M repeat the last one (their H is -big)
+                for (int c = wave; c < (nGs + 1) / 2; c += NW)
+                    glds4(prm.h + (long)b * M + min(j0 + c * 64 + lane, M - 1), &tileVBuf[buf * kTileV + c * 64]);
+            }
+        };
+        if (PRE && pre_js < pre_je) stage(pre_js, 0);
+        int pre_t = 0;
+
         for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
             int js, je;
-            column_interval<SPARSE>(rg, M, q, split, ns, js, je);
+            if (PRE) { js = pre_js; je = pre_je; }
+            else column_interval<SPARSE>(rg, M, q, split, ns, js, je);
             for (int j0 = js; j0 < je; j0 += kTileD) {
                 const int n = min(kTileD, je - j0);
                 const int npad = (n + 31) & ~31;
-                __syncthreads();
-                for (int t = tid; t < npad; t += kThreads)
-                    pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tile[(t >> 5) * (32 * NBP) + (t & 31)], 32,
-                                               &tileV[MODE == XD_GAUSS ? t : 0]);
-                __syncthreads();
+                const uint4* tile = tileBuf;
+                const float* tileV = tileVBuf;
+                if (PRE) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's share of tile t has landed ...
+                    __syncthreads();                                      // ... and so has everybody's; tile t - 1 is consumed
+                    if (j0 + kTileD < je) stage(j0 + kTileD, (pre_t + 1) & 1);
+                    tile = tileBuf + (pre_t & 1) * (kTileD * NBP);
+                    tileV = tileVBuf + (MODE == XD_GAUSS ? (pre_t & 1) * kTileV : 0);
+                    ++pre_t;
+                } else {
+                    __syncthreads();
+                    for (int t = tid; t < npad; t += kThreads)
+                        pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32,
+                                                   &tileVBuf[MODE == XD_GAUSS ? t : 0]);
+                    __syncthreads();
+                }
                 if (!wave_active) continue;
 
                 const int nG = npad / 32;

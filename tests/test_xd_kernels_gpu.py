@@ -65,6 +65,38 @@ def test_softmin_fwd_large_launch_paths(cuda, D, N, M):
     assert np.abs(out - alt).max() < 2 * _tol(ref, D)             # every row, against the unsplit launch
 
 
+@pytest.mark.parametrize("D,N,M", [(4, 33_000, 70_001), (8, 34_000, 66_000), (13, 33_333, 65_537), (16, 33_000, 70_001)])
+def test_prepacked_columns_and_lds_dma_path(cuda, D, N, M):
+    """Big dense launches (>= 5e8 pairs, >= 32768 rows, M >= 65536: 8-wavefront workgroups on the XCD-aware grid) run on PRE-PACKED
+    columns: `xd_pack_kernel` writes the bf16x3 records of every column once and the reducing workgroups stream whole tiles into
+    two LDS buffers with `global_load_lds_dwordx4` (glhip_softmin_xd.h).  M not a multiple of 32 (neutral padding columns, a short
+    last tile in the last split), late maxima, the fused half-step and the gaussian product (weights travel by 4-byte LDS-DMA),
+    against the float64 oracle on sampled rows — among them the first and last row blocks."""
+    x, y, h = _clouds(3 * D + 1, N, M, D)
+    h[-5:] += 30.0                                   # late maxima in the very last (short) tile
+    eps = 0.07**2 * D / 3
+    rows = np.unique(np.r_[0, 1, 255, 256, 511, 512, N - 513, N - 1, np.random.default_rng(2).integers(0, N, 120)])
+    sel = torch.from_numpy(rows).to(cuda)
+    xt, yt, ht = _t(x, cuda), _t(y, cuda), _t(h, cuda)
+    ref = o64.softmin(eps, x, y, h, rows=rows, device=cuda)
+    out = hip.softmin(eps, xt, yt, ht)
+    assert np.abs(out[sel].cpu().numpy() - ref).max() < _tol(ref, D)
+    ws = hip.load_library().glhip_workspace_bytes(1, N, M, D, 0)
+    assert ws >= ((M + 31) // 32) * 32 * 2 * ((D + 2) // 2) * 16          # the packed records are part of the workspace contract
+    # same bits from a second call (the pack kernel and the reducing kernel derive the launch centre independently)
+    assert torch.equal(out, hip.softmin(eps, xt, yt, ht))
+    pot = _t((np.random.default_rng(4).standard_normal(M) * 0.05).astype(np.float32), cuda)
+    prev = _t(np.random.default_rng(5).standard_normal(N).astype(np.float32), cuda)
+    fused = hip.sinkhorn_step(eps, xt, yt, ht, pot, prev, 0.8)
+    unfused = 0.5 * (prev + 0.8 * hip.softmin(eps, xt, yt, ht + pot / eps))
+    assert (fused - unfused).abs().max().item() < 2e-6
+    v = _t(((np.random.default_rng(6).random(M) - 0.3) / M).astype(np.float32), cuda)      # signed weights
+    blur = 0.2 * math.sqrt(D / 3)
+    refk = o64.kconv("gaussian", x, y, v.cpu().numpy(), blur, rows=rows, device=cuda)
+    outk = hip.kernel_conv("gaussian", xt, yt, v, blur)
+    assert relerr(outk[sel].cpu().numpy(), refk) < 1e-4
+
+
 def test_softmin_batched_bf16_and_fused_step(cuda):
     B, N, M, D = 3, 257, 300, 6
     x, y, logw = _clouds(3, N, M, D, B=B)
@@ -85,11 +117,19 @@ def test_softmin_batched_bf16_and_fused_step(cuda):
     first = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping).cpu().numpy()
     ref1 = damping * np.stack([oracle_c.softmin(eps, x[b], y[b], logw[b], 2) for b in range(B)])
     assert np.abs(first - ref1).max() < _tol(ref1, D)
-    with pytest.raises(NotImplementedError):       # p = 1 has no fused kernel beyond D = 3, nothing has beyond D = 16
-        hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping, p=1)
-    with pytest.raises(NotImplementedError):
-        hip.sinkhorn_step(eps, torch.rand(10, 17, device=cuda), torch.rand(12, 17, device=cuda), torch.zeros(12, device=cuda),
-                          None, None, 0.5)
+    # p = 1 has no fused kernel beyond D = 3, nothing has beyond D = 16, and NO_MFMA / DIRECT switch the matrix-core kernel off:
+    # hip.sinkhorn_step then composes the soft-min kernel with torch arithmetic (round 3 raised NotImplementedError here)
+    assert not hip.fused_step_applies(D, 1) and not hip.fused_step_applies(17, 2) and not hip.fused_step_applies(D, 2, hip.FLAG_NO_MFMA)
+    for kw in (dict(p=1), dict(flags=hip.FLAG_NO_MFMA), dict(flags=hip.FLAG_DIRECT)):
+        p = kw.get("p", 2)
+        want = 0.5 * (_t(prev, cuda) + damping * hip.softmin(eps, xt, yt, _t(logw + pot / np.float32(eps), cuda), **kw))
+        got = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), _t(pot, cuda), _t(prev, cuda), damping, **kw)
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6, kw
+        if p == 2:
+            assert (got - unfused).abs().max().item() < 3e-5 * max(1.0, unfused.abs().max().item()), kw
+    x17, y17 = torch.rand(10, 17, device=cuda), torch.rand(12, 17, device=cuda)
+    got = hip.sinkhorn_step(eps, x17, y17, torch.zeros(12, device=cuda), None, None, 0.5)
+    assert torch.allclose(got, 0.5 * hip.softmin(eps, x17, y17, torch.zeros(12, device=cuda)), rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize("D", [4, 5, 16])

@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -
 cd $REPO
 python - <<PY > $OUT/summary.txt
 import sqlite3, glob, collections
-print("# rocprofv3 over tools/$SCRIPT (N = M = 1e6, D = 3, fp32; 2 launches of each reduction); MI355X")
+print("# rocprofv3 over tools/$SCRIPT (N = M = 1e6, fp32; 2 launches of each reduction); MI355X")
 for db in glob.glob("$OUT/trace/**/*.db", recursive=True):
     c = sqlite3.connect(db)
     print("## --kernel-trace --stats (top_kernels): calls, average us, % of GPU time")
