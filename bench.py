@@ -425,6 +425,24 @@ def run_sharded(args, dev, rank, world):
     elapsed = t.item()
     devs = [None] * world                      # which device every rank really computed on: the curve's n_gpus must be real GPUs
     dist.all_gather_object(devs, f"{os.uname().nodename}:cuda{dev.index}")
+    # Attribution, OUTSIDE the timed region: what a sub-linear point of the curve is made of.  (a) every rank's own shard without
+    # any collective (its kernels + launches), (b) the scalar all-reduce alone; the rest of ms_per_step is waiting for the slowest rank.
+    reps = max(2, min(args.steps, 5))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        local = loss.loss(x, y).sum()
+    torch.cuda.synchronize()
+    local_ms = (time.perf_counter() - t1) / reps * 1e3
+    scalar = local.detach().clone()
+    fence()
+    t2 = time.perf_counter()
+    for _ in range(20):
+        dist.all_reduce(scalar)
+    torch.cuda.synchronize()
+    allreduce_ms = (time.perf_counter() - t2) / 20 * 1e3
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "problems": hi - lo, "local_loss_ms": round(local_ms, 4), "allreduce_ms": round(allreduce_ms, 4)})
     if rank == 0:
         pairs = cfg4_pairs(B)
         print(json.dumps({
@@ -442,6 +460,14 @@ def run_sharded(args, dev, rank, world):
                 "single_gpu_point": "`sharded_batch_reference` of the N=1 line (same workload, whole batch on one GPU)",
             },
             "loss_sum": float(total),
+            "per_rank_ms": [r["local_loss_ms"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+            "allreduce_ms": max(r["allreduce_ms"] for r in per_rank),
+            "attribution": {
+                "note": "measured after the timed region: per_rank_ms = each rank's shard alone, no collective (kernels + launches); "
+                        "allreduce_ms = one scalar all-reduce (slowest rank, 20 back to back); ms_per_step - max(per_rank_ms) - "
+                        "allreduce_ms = waiting on the slowest rank + the barrier of the protocol",
+                "problems_per_rank": [r["problems"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+            },
         }), flush=True)
 
 

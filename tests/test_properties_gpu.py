@@ -211,6 +211,9 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(cuda):
     ref = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)(x, y).sum().item()
     assert abs(rec["loss_sum"] - ref) <= 1e-6 * abs(ref)
     assert abs(rec["config"]["pairs_per_step"] - 6 * 40 * 4096.0**2) < 1
+    # attribution of a sub-linear point (measured after the timed region): one local time per rank, the bare all-reduce
+    assert len(rec["per_rank_ms"]) == 2 and all(t > 0 for t in rec["per_rank_ms"]) and rec["allreduce_ms"] > 0
+    assert rec["attribution"]["problems_per_rank"] == [3, 3]
 
 
 def test_bench_gpus2_without_torchrun(cuda):
