@@ -166,6 +166,37 @@ __device__ __forceinline__ void open_interval(const Ranges& rg, int M, int q_end
     }
 }
 
+// Block-sparse launches with pre-packed columns GATHER their tiles: a tile is the next (up to) kTileX columns of the concatenation
+// of the workgroup's column intervals, whatever their lengths, instead of one tile (stage + barrier + MFMAs + barrier) per piece
+// of an interval.  The reference's cluster_scale rule makes ~2000 clusters whatever N is, so at N = 1e4 a row block of 5 points
+// walks ~600 intervals of a few columns each (round 3: 156 us per soft-min against 10 us for the dense kernel on the same
+// points), and at N = 1e6 (455 columns per cluster, runs of 1-3 kept clusters) a third of the tiles were short tails.
+// gather_tile: the columns of slots t = tid + k * THREADS of the tile that starts at cursor c (-1: padding), the number of real
+// columns of the tile, and the cursor after it.  The walk over the intervals is wave-uniform (scalar loads and loop control).
+template <int K, int THREADS>
+__device__ __forceinline__ TileCursor gather_tile(const Ranges& rg, int M, int q_end, int split, int ns, TileCursor c, int tid,
+                                                  int (&cols)[K], int& n) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) cols[k] = -1;
+    int off = 0;
+    while (c.q < q_end && off < kTileX) {
+        const int len = min(c.je - c.j0, kTileX - off);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int t = tid + k * THREADS - off;
+            if (t >= 0 && t < len) cols[k] = c.j0 + t;
+        }
+        off += len;
+        c.j0 += len;
+        if (c.j0 >= c.je) {
+            c.q += ns;
+            open_interval<true, true>(rg, M, q_end, split, ns, c);
+        }
+    }
+    n = off;
+    return c;
+}
+
 // The work of one workgroup: row block bx of batch item b, column split `split`.  tileX: kTileX * 4 records of LDS,
 // [column group of 32][K block][column], one 16-byte record per (column, K block).
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
@@ -229,19 +260,43 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         cur.q = q_begin + (SPARSE ? split : 0);
         cur.j0 = cur.je = 0;
         open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, cur);
-        if (PRE && cur.q < q_end)
+        constexpr bool GATHER = SPARSE && PRE;   // pre-packed: the gathered tile is fetched into registers one tile ahead
+        constexpr bool GATHER_NOW = SPARSE && !PRE;   // packed on the fly: gathered when it is staged
+        constexpr int kCols = kPer / 4;          // columns a thread moves per tile
+        int gcols[kCols], gn = 0;                // GATHER: the columns behind `pre`, and how many real ones the fetched tile holds
+        TileCursor gnext = cur;                  // GATHER: the cursor after the fetched tile
+        auto fetch_gathered = [&]() {
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) {
+                const u32x4* col = reinterpret_cast<const u32x4*>(pk.rec + ((long)b * M + max(gcols[k], 0)) * 4);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) pre[k * 4 + kb] = col[kb];
+            }
+        };
+        if (GATHER) {
+            if (cur.q < q_end) {
+                gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn);
+                fetch_gathered();
+            }
+        } else if (PRE && cur.q < q_end) {
             fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(cur.j0), min(kTileX, cur.je - cur.j0), tid);
+        }
 
         while (cur.q < q_end) {
             {
                 const int j0 = cur.j0;
-                const int n = min(kTileX, cur.je - j0);
+                if (GATHER_NOW) gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn);
+                const int n = (GATHER || GATHER_NOW) ? gn : min(kTileX, cur.je - j0);
                 const int npad = (n + 31) & ~31;
                 TileCursor nxt = cur;   // the tile after this one
-                nxt.j0 += kTileX;
-                if (nxt.j0 >= nxt.je) {
-                    nxt.q += SPARSE ? ns : 1;
-                    open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, nxt);
+                if (GATHER || GATHER_NOW) {
+                    nxt = gnext;
+                } else {
+                    nxt.j0 += kTileX;
+                    if (nxt.j0 >= nxt.je) {
+                        nxt.q += SPARSE ? ns : 1;
+                        open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, nxt);
+                    }
                 }
                 __syncthreads();
                 if (PRE && !SPARSE) {
@@ -256,16 +311,27 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                         const int t = tid + k * kThreads;
                         if (t < npad) {
                             u32x4* dst = reinterpret_cast<u32x4*>(&tileX[(t >> 5) * 128 + (t & 31)]);
-                            const bool real = t < n;
+                            const bool real = t < n;      // (gathered tiles fill their slots in order: the same test)
 #pragma unroll
                             for (int kb = 0; kb < 3; ++kb) dst[kb * 32] = real ? pre[k * 4 + kb] : u32x4{0u, 0u, 0u, 0u};
                             dst[96] = real ? pre[k * 4 + 3] : neutral_h;
                         }
                     }
                 }
-                if (PRE) {
+                if (GATHER) {
+                    if (nxt.q < q_end) {
+                        gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, nxt, tid, gcols, gn);
+                        fetch_gathered();
+                    }
+                } else if (PRE) {
                     if (nxt.q < q_end)
                         fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(nxt.j0), min(kTileX, nxt.je - nxt.j0), tid);
+                } else if (GATHER_NOW) {
+#pragma unroll
+                    for (int k = 0; k < kCols; ++k) {
+                        const int t = tid + k * kThreads;
+                        if (t < npad) pack_column<D, T>(prm, (long)b * M + max(gcols[k], 0), t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)], 32);
+                    }
                 } else {
                     for (int t = tid; t < npad; t += kThreads)
                         pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)], 32);

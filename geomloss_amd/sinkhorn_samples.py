@@ -328,8 +328,13 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     x_, yd_, ranges_x_, ranges_y_, _ = C_xy_
     y_, xd_, _, _, _ = C_yx_
     native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
-    if native_p is not None and not verbose and native_clustering_applies(x):
+    if native_p is not None and native_clustering_applies(x):
         ranges_xy_ = block_ranges_device("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps, p=native_p)
+        if verbose:     # the printed statistic only: the ranges above are the ones a silent run builds (same kernels either way)
+            with torch.no_grad():
+                C = cost(x, y)
+                ks, Cs = (f_ba.view(-1, 1) + g_ab.view(1, -1) > C - truncate * eps).sum(), C.shape[0] * C.shape[1]
+            print("Keep {}/{} = {:2.1f}% of the coarse cost matrix.".format(ks, Cs, 100 * float(ks) / Cs))
         return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
     with torch.no_grad():
         C = cost(x, y)

@@ -120,6 +120,25 @@ def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling):
     assert relerr(Fm.cpu().numpy(), Fo) < 1e-4 and relerr(Gm.cpu().numpy(), Go) < 1e-4
 
 
+def test_multiscale_verbose_runs_the_same_kernels(cuda, capsys):
+    """verbose=True prints the reference's lines (``_legacy/sinkhorn_samples.py:516-522,599-618``) and must not change what is
+    computed: round 3 sent verbose runs down the torch keep-mask path; now the block-sparse ranges come from glhip_block_ranges
+    either way and the printed percentage is an extra statistic.  Same bits with and without."""
+    x, y = _two_clouds(5, 4000, 3800, kind="shifted")
+    xt, yt = torch.from_numpy(x).to(cuda), torch.from_numpy(y).to(cuda)
+    kw = dict(p=2, blur=0.05, scaling=0.6, backend="multiscale")
+    quiet = SamplesLoss("sinkhorn", **kw)(xt, yt)
+    capsys.readouterr()
+    loud = SamplesLoss("sinkhorn", verbose=True, **kw)(xt, yt)
+    text = capsys.readouterr().out
+    assert torch.equal(quiet, loud)
+    assert "clusters, computed at scale" in text and "Successive scales" in text and "Jump from coarse to fine" in text
+    keeps = [l for l in text.splitlines() if l.startswith("Keep ")]
+    assert len(keeps) == 3 and all("% of the coarse cost matrix." in l for l in keeps)        # C_xy, C_xx, C_yy
+    pct = [float(l.split("=")[1].split("%")[0]) for l in keeps]
+    assert all(0.0 < p < 100.0 for p in pct)
+
+
 def test_multiscale_jump_after_last_iteration_and_labels(cuda):
     """diameter=1 recipe of the reference benchmark: the jump lands on the last iteration (pure extrapolation)."""
     N, M = 2500, 2600
