@@ -12,7 +12,7 @@ int glhip_version(void) { return GLHIP_VERSION; }
 
 size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
     if (B <= 0 || N <= 0 || M <= 0 || D < 1 || D > kXdMaxD) return 0;   // the generic-D kernels (D > 16) do not split
-    if (D > 3) {   // 4 <= D <= 16 (glhip_softmin_xd.h): split partials of 2 floats per row, no packed columns
+    if (D > 3) {   // 4 <= D <= 16 (glhip_softmin_xd.h): split partials of 2 floats per row (+ packed columns on big dense launches)
         const int ns128 = choose_splits(n_ranges > 0 ? n_ranges : (long)B * ((N + 127) / 128), M, n_ranges, 1L << 30);
         int nf = ns128;
         if (n_ranges == 0 && M >= 65536) {
@@ -29,8 +29,8 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
             ng = ng > nx ? ng : nx;
         }
         const size_t grad = (size_t)(ng < 2 ? 0 : ng) * (size_t)B * (size_t)N * (size_t)(D + 1) * sizeof(float);
-        if (n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8)    // forward, big dense launches: + the pre-packed column records
-            bytes += 256 + (size_t)B * (size_t)((M + 31) / 32) * 32 * (size_t)(2 * ((D + 2) / 2)) * sizeof(uint4);
+        if (n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8)    // forward, big dense launches: up to 32 splits (one split's records per XCD L2) + the pre-packed column records
+            bytes = (size_t)32 * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 + (size_t)B * (size_t)((M + 31) / 32) * 32 * (size_t)(2 * ((6 * (D + 1) + 15) / 16)) * sizeof(uint4);   // XdShape<D>::NBP records per column
         bytes = bytes > grad ? bytes : grad;
         if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);
         return bytes;

@@ -421,11 +421,18 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
 template <int MODE, int D, typename T, class MergeOp>
 void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N, int M,
                const Scratch& sc, hipStream_t st) {
-    // big launches: 8 wavefronts x 2 row tiles (512 rows share the bf16 pieces of a column; 1 tile from D = 9 up, where the
-    // x-side operands of two tiles would not fit 128 VGPRs); small ones: 4 wavefronts x 1 tile, more workgroups
+    // big launches: 8 wavefronts x 2 row tiles (the two tiles share the LDS reads of a column group; 512 rows share the bf16
+    // pieces of a column when they are packed on the fly) while the x-side operands of two tiles fit 128 VGPRs — 4 waves per
+    // SIMD: up to 5 chained MFMAs (D <= 12) on dense launches, 4 (D <= 9) on block-sparse ones, 1 tile beyond; small launches:
+    // 4 wavefronts x 1 tile, more workgroups
+    constexpr int NM = XdShape<D>::NM;
     const bool big = (double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192);
-    if (big) launch_xd_cfg<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
-    else launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    if (big) {
+        if (NM <= 4 || (NM == 5 && n_ranges == 0)) launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+        else launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    } else {
+        launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    }
 }
 
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum

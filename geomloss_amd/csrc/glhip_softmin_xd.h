@@ -1,14 +1,22 @@
 // glhip_softmin_xd.h — the bf16x3 matrix-core reductions for clouds of dimension 4 <= D <= 16: soft-min forward (p = 2, incl. the
 // fused Sinkhorn half-step) and gaussian kernel product.
 //
-// Same arithmetic and the same transposed 32 x 32 blocks as glhip_softmin_x32.h (D <= 3): every fp32 operand is the exact sum of
-// three bf16 pieces, one coordinate fills one K block of 8 slots ([y1,y2,y1,y3,y1,y2,y3,y2] against [a1,a1,a2,a1,a3,a2,a2,a3]),
-// one more block carries the per-column scalar and the per-row constant ([H1,H2,H3,1,1,1,0,0] against [1,1,1,n1,n2,n3,0,0]).  A
-// v_mfma_f32_32x32x16_bf16 takes two K blocks (lanes 0-31 hold the even one, lanes 32-63 the odd one), so a block of exponents
-// is a chain of NM = ceil((D + 1) / 2) MFMAs instead of 2: 3 for D = 4, 5; 5 for D = 8; 9 for D = 16.  The VALU work per pair does
-// not depend on D — one v_exp_f32 and one v_add_f32 (soft-min) or v_fma_f32 (gaussian) — and a 32x32x16 MFMA costs 32 cycles of
-// matrix pipe per 1024 pairs against ~200 cycles of that VALU stream, so up to D ~ 10 the chain hides behind the exponentials;
-// beyond, the kernel becomes matrix-pipe bound (9 x 32 = 288 cycles per 1024 pairs at D = 16).
+// Same transposed 32 x 32 blocks as glhip_softmin_x32.h (D <= 3) and the same idea — every fp32 operand is the exact sum of three
+// bf16 pieces and an exponent is a short dot product on v_mfma_f32_32x32x16_bf16 — with a denser K layout (round 4).  A coordinate
+// takes SIX slots, the products a1 y1, a1 y2, a2 y1, a1 y3, a3 y1, a2 y2 ([y1,y2,y1,y3,y1,y2] against [a1,a1,a2,a1,a3,a2]); the
+// two products of relative size 2^-24 that the 8-slot layout of the D <= 3 kernels also carries (a2 y3, a3 y2) are dropped.  The
+// pieces are split with ROUND-TO-NEAREST here (signed residuals half as large as truncated ones: |a2| <= 2^-9 |a|, |a3| <= 2^-17
+// |a|), so the dropped terms are <= 2^-25 |a y| each, of either sign: below the 2^-24 rounding of a float32 product, and of the
+// float32 accumulation inside the MFMA.  One more item of six slots carries the per-column scalar and the per-row constant
+// ([H1,H2,H3,1,1,1] against [1,1,1,n1,n2,n3]); it comes FIRST, so that it always lies in the first 16-byte record of lane half 0.
+// The items are laid end to end over the K dimension: 6 (D + 1) slots = NM = ceil(6 (D + 1) / 16) chained MFMAs —
+//     D      4  5  6  7  8  9  10  11  12  13  14  15  16
+//     NM     2  3  3  3  4  4   5   5   5   6   6   6   7        (8-slot layout of round 3: 3 3 4 4 5 5 6 6 7 7 8 8 9)
+// Why the count matters (tools/ubench/chain.hip, profiles/r04_ubench_chain.txt, r04_xd_pmc.txt): next to the 16 v_exp_f32 +
+// 16 v_add_f32 of a block every MFMA costs ~13 issue cycles while the VALU is the bound (200 + 13 NM cycles per 1024 pairs up to
+// NM ~ 5) and its full 32-36 cycles beyond; the two pipes do overlap across the wavefronts of a SIMD, an in-wave software pipeline
+// adds nothing from 2 waves per SIMD on; and the chip clocks down with the matrix load (2.22 GHz at D = 3, 1.94 at NM = 5,
+// 1.74 at NM = 9).  Fewer MFMAs is the one lever that pays twice.
 //
 // The reference takes any D (`Vi({D})` in lse_genred, _legacy/sinkhorn_samples.py:322-334; its multiscale tutorial is 4-D:
 // examples/sinkhorn_multiscale/plot_optimal_transport_cluster.py:58-61); before this header every D >= 4 went to the
@@ -35,17 +43,64 @@ enum XdMode { XD_SOFTMIN = 0, XD_GAUSS = 1 };
 template <int D>
 struct XdShape {
     static_assert(D >= 4 && D <= 16, "glhip_softmin_xd.h serves 4 <= D <= 16");
-    static constexpr int NB = D + 1;                 // K blocks in use: D coordinates + the scalar block
-    static constexpr int NM = (NB + 1) / 2;          // chained MFMAs per 32 x 32 block
-    static constexpr int NBP = 2 * NM;               // records per column in LDS
+    static constexpr int kSlots = 6 * (D + 1);       // scalar item (slots 0..5), then 6 slots per coordinate
+    static constexpr int NM = (kSlots + 15) / 16;    // chained MFMAs per 32 x 32 block
+    static constexpr int NBP = 2 * NM;               // records (8 slots, 16 bytes) per column in LDS: record r = slots [8 r, 8 r + 8)
     static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);   // columns per LDS tile (on-the-fly staging)
     // pre-packed columns: two tile buffers of at most 2304 records (36 KiB) each — two 8-wave workgroups per CU hold 144 of the
-    // 160 KiB — in whole groups of 32 columns: 384 columns at D = 4, 5 ... 128 at D = 14 .. 16
+    // 160 KiB — in whole groups of 32 columns
     static constexpr int kTilePre = (2304 / NBP) / 32 * 32;
     static constexpr int kGroupRecs = 32 * NBP;      // records of one column group = NM chunks of 64 records (1 KiB)
-    static constexpr int HM = D / 2;                 // the scalar block is K block D: MFMA D / 2 ...
-    static constexpr int HH = D % 2;                 // ... lane half D % 2
 };
+
+// fp32 -> three bf16 pieces whose sum is exact, split with round-to-nearest-even (the residuals are signed and at most half a
+// unit of the piece before them).  inf / nan stay in the first piece.
+__device__ __forceinline__ void split3_rn(float v, uint32_t (&p)[3]) {
+    const uint32_t u = __float_as_uint(v);
+    const bool special = (u & 0x7F800000u) == 0x7F800000u;
+    const uint32_t b1 = special ? (u & 0xFFFF0000u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+    const float r = special ? 0.f : v - __uint_as_float(b1);                      // exact
+    const uint32_t ur = __float_as_uint(r);
+    const uint32_t b2 = (ur + 0x7FFFu + ((ur >> 16) & 1u)) & 0xFFFF0000u;
+    const float r2 = r - __uint_as_float(b2);                                      // exact, at most 8 significant bits
+    p[0] = b1 >> 16;
+    p[1] = b2 >> 16;
+    p[2] = __float_as_uint(r2) >> 16;
+}
+
+constexpr uint32_t kBf16One = 0x3F80u;
+
+// bf16 value of K slot `slot` of a column (y side) or of a row (x side): sc = pieces of the scalar item (H_j | n_i),
+// cp[d] = pieces of coordinate d.  All indices are compile-time constants after unrolling.
+template <int D, bool XSIDE>
+__device__ __forceinline__ uint32_t xd_slot(int slot, const uint32_t (&sc)[3], const uint32_t (&cp)[D][3]) {
+    if (slot >= 6 * (D + 1)) return 0u;
+    if (slot < 6) {
+        if (XSIDE) return slot < 3 ? kBf16One : sc[slot - 3];     // [1,1,1,n1,n2,n3]
+        return slot < 3 ? sc[slot] : kBf16One;                    // [H1,H2,H3,1,1,1]
+    }
+    const int d = (slot - 6) / 6, t = (slot - 6) % 6;
+    const int piece = XSIDE ? (t == 2 ? 1 : (t == 4 ? 2 : (t == 5 ? 1 : 0)))        // [a1,a1,a2,a1,a3,a2]
+                            : (t == 1 ? 1 : (t == 3 ? 2 : (t == 5 ? 1 : 0)));       // [y1,y2,y1,y3,y1,y2]
+    return cp[d][piece];
+}
+
+// record r (slots 8 r .. 8 r + 7) of a column / a row
+template <int D, bool XSIDE>
+__device__ __forceinline__ uint4 xd_record(int r, const uint32_t (&sc)[3], const uint32_t (&cp)[D][3]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        w[k] = xd_slot<D, XSIDE>(8 * r + 2 * k, sc, cp) | (xd_slot<D, XSIDE>(8 * r + 2 * k + 1, sc, cp) << 16);
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+
+// x side, record 0 of lane half 0 = [1,1,1,n1,n2,n3, coordinate 0: a1, a1]: replaces n (soft-min: minus the running maximum)
+__device__ __forceinline__ uint4 xd_with_n(const uint4& rec0, float n) {
+    uint32_t p[3];
+    split3_rn(n, p);
+    return uint4{rec0.x, kBf16One | (p[0] << 16), p[1] | (p[2] << 16), rec0.w};
+}
 
 // One column as NBP records `stride` apart starting at `base`; coordinates relative to `centre`.
 //   XD_SOFTMIN: H = log2(e) h_j - s/2 |yt|^2  (h_j through dual_entry: the fused half-step adds pot_j / eps)
@@ -74,10 +129,12 @@ __device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long
             vj = prm.h[col];
         }
     }
+    uint32_t sc[3], cp[D][3];
+    split3_rn(H, sc);
 #pragma unroll
-    for (int d = 0; d < D; ++d) base[d * stride] = pack_y(yt[d]);
-    base[D * stride] = pack_h1(H);
-    if (S::NBP > S::NB) base[S::NB * stride] = uint4{0u, 0u, 0u, 0u};
+    for (int d = 0; d < D; ++d) split3_rn(yt[d], cp[d]);
+#pragma unroll
+    for (int r = 0; r < S::NBP; ++r) base[r * stride] = xd_record<D, false>(r, sc, cp);
     if (MODE == XD_GAUSS) *vdst = vj;
 }
 
@@ -162,9 +219,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
     block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const uint4 kOnes = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // [1,1,1,0,...]: the scalar block with n = 0
-    const uint4 kZero = uint4{0u, 0u, 0u, 0u};
-    const bool owns_h = (half == S::HH);                          // this lane's half carries the scalar block in MFMA HM
+    const bool owns_h = (half == 0);        // the scalar item (slots 0..5) lies in record 0: lane half 0 of the first MFMA
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
@@ -187,20 +242,15 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                 n2 = __builtin_fmaf(xt, xt, n2);
                 a[d] = xt * prm.s2;
             }
-            // scalar block of the x side: [1,1,1,n1,n2,n3]; soft-min: n = -running max (0 until the first group has been seen),
+            // scalar item of the x side: [1,1,1,n1,n2,n3]; soft-min: n = -running max (0 until the first group has been seen),
             // gaussian: n = r_i = -s/2 |xt_i|^2, constant
-            const uint4 hblk = (MODE == XD_SOFTMIN) ? kOnes : pack_negmax(0.5f * prm.s2 * n2);
+            uint32_t sc[3], cp[D][3];
+            split3_rn((MODE == XD_SOFTMIN) ? 0.f : -0.5f * prm.s2 * n2, sc);
 #pragma unroll
-            for (int mm = 0; mm < NM; ++mm) {
-                const int kb0 = 2 * mm, kb1 = 2 * mm + 1;
-                // the coordinate this lane packs for MFMA mm (its half's K block), when that block is a coordinate
-                const float av = (kb1 < D) ? (half ? a[kb1 < D ? kb1 : 0] : a[kb0]) : a[kb0 < D ? kb0 : 0];
-                uint4 pa = pack_a(av);
-                if (kb0 == D) pa = hblk;                                  // D even: the scalar block sits in half 0 of the last MFMA
-                if (kb1 == D) pa = select_u4(half != 0, hblk, pa);        // D odd: in half 1
-                if (kb1 > D) pa = select_u4(half != 0, kZero, pa);        // D even: half 1 of the last MFMA is the zero pad
-                X[rt][mm] = pa;
-            }
+            for (int d = 0; d < D; ++d) split3_rn(a[d], cp[d]);
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm)     // this lane's half of MFMA mm: record 2 mm + half
+                X[rt][mm] = select_u4(half != 0, xd_record<D, true>(2 * mm + 1, sc, cp), xd_record<D, true>(2 * mm, sc, cp));
             m[rt] = kMinusHuge;
             ssum[rt] = 0.f;
         }
@@ -272,7 +322,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         um = fmaxf(um, kMinusHuge);
                         m[rt] = um;
                         ssum[rt] = sum_exp2_16(u, um);
-                        X[rt][S::HM] = select_u4(owns_h, pack_negmax(um), X[rt][S::HM]);
+                        X[rt][0] = select_u4(owns_h, xd_with_n(X[rt][0], -um), X[rt][0]);
                     }
                     first_group = false;
                     G0 = 1;
@@ -298,7 +348,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                             uint4 Xp[NM];
 #pragma unroll
                             for (int mm = 0; mm < NM; ++mm) Xp[mm] = X[rt][mm];
-                            Xp[S::HM] = select_u4(owns_h, kOnes, Xp[S::HM]);              // n = 0: plain exponents
+                            Xp[0] = select_u4(owns_h, xd_with_n(Xp[0], 0.f), Xp[0]);      // n = 0: plain exponents
                             const f32x16 u = xd_block<NM, NBP>(g, rec0, Xp, zero16);
                             float um = max16(u);
                             um = fmaxf(um, __shfl_xor(um, 32, 64));
@@ -308,7 +358,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         }
                     }
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) X[rt][S::HM] = select_u4(owns_h, pack_negmax(m[rt]), X[rt][S::HM]);
+                    for (int rt = 0; rt < RT; ++rt) X[rt][0] = select_u4(owns_h, xd_with_n(X[rt][0], -m[rt]), X[rt][0]);
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];

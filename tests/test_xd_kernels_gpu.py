@@ -82,7 +82,7 @@ def test_prepacked_columns_and_lds_dma_path(cuda, D, N, M):
     out = hip.softmin(eps, xt, yt, ht)
     assert np.abs(out[sel].cpu().numpy() - ref).max() < _tol(ref, D)
     ws = hip.load_library().glhip_workspace_bytes(1, N, M, D, 0)
-    assert ws >= ((M + 31) // 32) * 32 * 2 * ((D + 2) // 2) * 16          # the packed records are part of the workspace contract
+    assert ws >= ((M + 31) // 32) * 32 * 2 * ((6 * (D + 1) + 15) // 16) * 16   # the packed records are part of the workspace contract
     # same bits from a second call (the pack kernel and the reducing kernel derive the launch centre independently)
     assert torch.equal(out, hip.softmin(eps, xt, yt, ht))
     pot = _t((np.random.default_rng(4).standard_normal(M) * 0.05).astype(np.float32), cuda)
