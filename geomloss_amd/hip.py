@@ -13,6 +13,7 @@ import os
 import warnings
 
 import torch
+from torch.autograd.function import once_differentiable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
@@ -540,6 +541,7 @@ class _Softmin(torch.autograd.Function):
         return out if batched else out.view(-1)
 
     @staticmethod
+    @once_differentiable        # second-order derivatives through the HIP soft-min: autograd raises if they are asked for (backend="tensorized" is differentiable to any order)
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise NotImplementedError(
@@ -567,6 +569,7 @@ class _SoftminValueGrad(torch.autograd.Function):
         return out if batched else out.view(-1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         xshape, xdtype = ctx.cfg
         g = grad_out.reshape(ctx.unit.shape[0], -1).float()
@@ -687,6 +690,7 @@ class _Last4(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *grads):
         plan = ctx.plan
         eps, damping, xshape, xdtype, yshape, ydtype = ctx.cfg
@@ -802,14 +806,24 @@ class _KernelConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kind, x, y, v, blur, ranges, flags, x_grad=True):
+        # x_grad: needs_input_grad says True for a leaf that requires gradients even under no_grad, where nothing will be asked for
+        xb, yb, vb, batched, out, unit = _KernelConv.product(kind, x, y, v, blur, ranges, flags, x_grad and ctx.needs_input_grad[1])
+        ctx.unit = unit
+        ctx.save_for_backward(xb, yb, vb, x, y, v)      # x, y, v themselves: the differentiable backward (create_graph) needs their history
+        ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
+        return out if batched else out.view(-1)
+
+    @staticmethod
+    def product(kind, x, y, v, blur, ranges, flags, want_unit):
+        """The launch behind forward: (xb, yb, vb, batched, out (B,N), unit (B,N,D) | None); unit_i = d out_i / d x_i when
+        ``want_unit`` and a product-and-gradient kernel exists for this kind and dimension."""
         xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
         # carries one more accumulator, the product itself.  The backward pass is then elementwise.
         # (D <= 3: every kernel; 4 <= D <= 16: the gaussian kernel on the matrix cores)
-        # x_grad: needs_input_grad says True for a leaf that requires gradients even under no_grad, where nothing will be asked for
-        fused = (_fuse_kernel_grad and x_grad and ctx.needs_input_grad[1]
+        fused = (_fuse_kernel_grad and want_unit
                  and (xb.shape[-1] <= 3 or (kind == GAUSSIAN and xb.shape[-1] <= XD_MAX_DIM and not (flags & FLAG_NO_MFMA))))
         # laplacian / energy: squared distances from the matrix cores wherever the row blocks are spatially compact — the voxel
         # clusters of the multiscale backend as they are, large dense launches after a voxel sort of both clouds (plan) — for the
@@ -837,14 +851,46 @@ class _KernelConv(torch.autograd.Function):
             out, unit = plan.unsort(out), (None if unit is None else plan.unsort(unit))
         elif rows is not None:
             out, unit = _unsort_rows(rows[0], out), (None if unit is None else _unsort_rows(rows[0], unit))
-        ctx.unit = unit
-        ctx.save_for_backward(xb, yb, vb)
-        ctx.cfg = (kind, blur, ranges, flags, x.shape, y.shape, v.shape, x.dtype, y.dtype, v.dtype)
-        return out if batched else out.view(-1)
+        return xb, yb, vb, batched, out, unit
+
+    @staticmethod
+    def _differentiable_backward(ctx, grad_out):
+        """backward under ``create_graph=True``: the three gradients written with differentiable operations, so that autograd can
+        go through them once more (KeOps' symbolic ``Grad`` composes the same way: ``_legacy/kernel_samples.py:43-54``).  Gaussian
+        kernel, dense: with s = 1 / blur^2 and k = exp(-s |x - y|^2 / 2),
+            d/dx_i = -s g_i [ x_i (K v)_i - (K (v y))_i ],   d/dy_j = s v_j [ (K^T (g x))_j - y_j (K^T g)_j ],   d/dv = K^T g
+        — D + 1 kernel products per cloud instead of one gradient reduction, each of them this very autograd function."""
+        kind, blur, ranges, flags = ctx.cfg[:4]
+        x, y, v = ctx.saved_tensors[3:]
+        g = grad_out.reshape(x.shape[:-1])
+        v = v.reshape(y.shape[:-1])
+        s = 1.0 / (blur * blur)
+        conv = lambda rows, cols, w: kernel_conv(kind, rows, cols, w, blur, None, flags & ~FLAG_GRAD_FAMILY)   # noqa: E731
+        D = x.shape[-1]
+        gx = gy = gv = None
+        if ctx.needs_input_grad[1]:
+            Kvy = torch.stack([conv(x, y, v * y[..., d]) for d in range(D)], dim=-1)
+            gx = (-s) * g.unsqueeze(-1) * (x * conv(x, y, v).unsqueeze(-1) - Kvy)
+        if ctx.needs_input_grad[2]:
+            Kgx = torch.stack([conv(y, x, g * x[..., d]) for d in range(D)], dim=-1)
+            gy = s * v.unsqueeze(-1) * (Kgx - y * conv(y, x, g).unsqueeze(-1))
+        if ctx.needs_input_grad[3]:
+            gv = conv(y, x, g)
+        return None, gx, gy, gv, None, None, None, None
 
     @staticmethod
     def backward(ctx, grad_out):
-        xb, yb, vb = ctx.saved_tensors
+        # create_graph=True: somebody may differentiate this gradient.  Dense gaussian products: the differentiable form; laplacian /
+        # energy / block-sparse ones: the one-reduction gradients below, marked once-differentiable (autograd raises if a second
+        # derivative is really taken through them; backend="tensorized" is differentiable to any order)
+        if torch.is_grad_enabled() and ctx.cfg[0] == GAUSSIAN and ctx.cfg[2] is None:
+            return _KernelConv._differentiable_backward(ctx, grad_out)
+        return _KernelConv._backward_once(ctx, grad_out)
+
+    @staticmethod
+    @once_differentiable
+    def _backward_once(ctx, grad_out):
+        xb, yb, vb = ctx.saved_tensors[:3]
         kind, blur, ranges, flags, xs, ys, vs, xdt, ydt, vdt = ctx.cfg
         g = grad_out.reshape(xb.shape[0], -1).float().contiguous()
         rt = None if ranges is None else ranges.t()
@@ -895,6 +941,29 @@ def kernel_conv(kind, x, y, v, blur=0.05, ranges=None, flags=0):
                              torch.is_grad_enabled() and x.requires_grad)
 
 
+def kernel_conv_with_unit(kind, x, y, v, blur, want_unit, flags=0):
+    """No autograd: ``(K v, d (K v)_i / d x_i | None)`` from one reduction where a product-and-gradient kernel exists (the building
+    block of kernel_samples._UnionNorm); shapes follow x: (N,), (N,D) or (B,N), (B,N,D)."""
+    kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
+    with torch.no_grad():
+        _, _, _, batched, out, unit = _KernelConv.product(kind, x, y, v, 1.0 if blur is None else float(blur), None, int(flags) | ENV_FLAGS,
+                                                          want_unit)
+    if not batched:
+        out, unit = out.view(-1), (None if unit is None else unit.view(-1, unit.shape[-1]))
+    return out, unit
+
+
+def kernel_conv_row_gradient(kind, x, y, v, g, blur, flags=0):
+    """No autograd: d/dx of sum_i g_i (K v)_i as one gradient reduction (``glhip_kernel_conv_bwd_x``), shaped like x."""
+    kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
+    with torch.no_grad():
+        xb, yb, vb, _ = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
+        if yb.dtype != xb.dtype:
+            yb = yb.to(xb.dtype)
+        gb = _f32(g).reshape(xb.shape[0], -1)
+        return _KernelConv._row_gradient(kind, xb, yb, vb, gb, 1.0 if blur is None else float(blur), None, int(flags) | ENV_FLAGS).reshape(x.shape)
+
+
 class _SoftminDense(torch.autograd.Function):
     """Row-wise soft-min of an explicit cost matrix (the tensorized backend on GPU tensors)."""
 
@@ -943,6 +1012,7 @@ class _LseLines(torch.autograd.Function):
         return out.to(h.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         hc, out = ctx.saved_tensors
         eps, p, dtype = ctx.cfg

@@ -177,6 +177,83 @@ def _upper_triangle_applies(name, pts):
             and (pts.dim() == 2 or pts.shape[0] == 1))
 
 
+class _UnionNorm(torch.autograd.Function):
+    """1/2 <w, K_zz w> on the union cloud z = (x, y), w = (α, -β), as ONE autograd node.
+
+    forward: the two row passes U_x = (K_zz w)|x, U_y = (K_zz w)|y, each together with d U_i / d z_i when its cloud takes a gradient
+    (one product-and-gradient reduction).  backward, first order: elementwise — d/dx_i = α_i d U_i / d x_i (the quadratic form is
+    symmetric: the derivative through the columns equals the one through the rows, which is what the reference's DoubleGrad
+    trick expresses, ``_legacy/kernel_samples.py:43-54,117-125``), d/dα = U_x, d/dβ = -U_y.
+    backward under ``create_graph=True`` (gaussian kernel): the same gradients written with differentiable kernel products of the
+    NON-detached clouds and weights, so that second derivatives are those of the loss itself — including the dependence through
+    the columns that a detached copy drops (the reference's Hessian of a self-term is incomplete for that reason)."""
+
+    @staticmethod
+    def forward(ctx, name, blur, α, x, β, y):
+        batch = x.dim() > 2
+        z = torch.cat((x, y.to(x.dtype)), dim=-2)
+        w = torch.cat((α.float(), -β.float()), dim=-1)
+        U_x, unit_x = hip.kernel_conv_with_unit(name, x, z, w, blur, ctx.needs_input_grad[3])
+        U_y, unit_y = hip.kernel_conv_with_unit(name, y, z, w, blur, ctx.needs_input_grad[5])
+        ctx.name, ctx.blur, ctx.units = name, blur, (unit_x, unit_y)
+        ctx.save_for_backward(α, x, β, y, U_x, U_y)
+        return 0.5 * scal_sum(α, U_x, β, -U_y, batch=batch)
+
+    @staticmethod
+    def backward(ctx, gL):
+        if torch.is_grad_enabled() and ctx.name == "gaussian":
+            return _UnionNorm._differentiable_backward(ctx, gL)
+        return _UnionNorm._backward_once(ctx, gL)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def _backward_once(ctx, gL):
+        α, x, β, y, U_x, U_y = ctx.saved_tensors
+        name, blur = ctx.name, ctx.blur
+        gl = gL.reshape(-1, 1) if x.dim() > 2 else gL.reshape(())           # one factor per batch item
+        gα = gβ = gx = gy = None
+        if ctx.needs_input_grad[2]:
+            gα = (gl * U_x).to(α.dtype).reshape(α.shape)
+        if ctx.needs_input_grad[4]:
+            gβ = (-gl * U_y).to(β.dtype).reshape(β.shape)
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
+            z = torch.cat((x, y.to(x.dtype)), dim=-2)
+            w = torch.cat((α.float(), -β.float()), dim=-1)
+
+            def rows(pts, wt, unit):     # d/d pts_i of 1/2 <w, K w> = wt_i d U_i / d pts_i
+                g = gl * wt.float()
+                if unit is not None:
+                    return (g.unsqueeze(-1) * unit).to(pts.dtype).reshape(pts.shape)
+                return hip.kernel_conv_row_gradient(name, pts, z, w, g, blur).to(pts.dtype)
+            if ctx.needs_input_grad[3]:
+                gx = rows(x, α, ctx.units[0])
+            if ctx.needs_input_grad[5]:
+                gy = rows(y, -β, ctx.units[1])
+        return None, None, gα, gx, gβ, gy
+
+    @staticmethod
+    def _differentiable_backward(ctx, gL):
+        α, x, β, y = ctx.saved_tensors[:4]
+        name, blur = ctx.name, ctx.blur
+        batch = x.dim() > 2
+        gl = gL.reshape(-1, 1) if batch else gL.reshape(())
+        s = 1.0 / (blur * blur)
+        z = torch.cat((x, y.to(x.dtype)), dim=-2)
+        w = torch.cat((α, -β), dim=-1).to(z.dtype)
+        D = x.shape[-1]
+
+        def rows(pts, wt, U):            # wt_i sum_j w_j grad_1 k(pts_i, z_j) = -s wt_i [ pts_i U_i - (K (w z))_i ]
+            Kwz = torch.stack([hip.kernel_conv(name, pts, z, w * z[..., d], blur) for d in range(D)], dim=-1)
+            return (gl * wt).unsqueeze(-1) * (-s) * (pts * U.unsqueeze(-1) - Kwz)
+        U_x = hip.kernel_conv(name, x, z, w, blur)
+        U_y = hip.kernel_conv(name, y, z, w, blur)
+        gα = gl * U_x if ctx.needs_input_grad[2] else None
+        gβ = -gl * U_y if ctx.needs_input_grad[4] else None
+        gx = rows(x, α, U_x) if ctx.needs_input_grad[3] else None
+        gy = rows(y, -β, U_y) if ctx.needs_input_grad[5] else None
+        return None, None, gα, gx, gβ, gy
+
+
 def _kernel_loss_union(α, x, β, y, blur, name, potentials):
     """The matrix-free dense kernel norm (or its potentials) on the union cloud: see the note above."""
     if name not in kernel_routines:
@@ -189,13 +266,18 @@ def _kernel_loss_union(α, x, β, y, blur, name, potentials):
         out = (0.5 * _quadratic_form_value(name, z, w, blur)).float()
         return out.view(1) if batch else out
 
-    # rows of x, rows of y: each differentiates through its own rows only, with a doubled gradient (the quadratic form is
-    # symmetric: ``:117-125`` plays the same trick on K_xx and K_yy); the columns and their weights are constants
+    if not potentials:
+        if _takes_no_gradient(α, x, β, y):
+            with torch.no_grad():
+                U_x, U_y = hip.kernel_conv(name, x, z, w, blur), hip.kernel_conv(name, y, z, w, blur)
+                return 0.5 * scal_sum(α, U_x, β, -U_y, batch=batch)
+        return _UnionNorm.apply(name, 1.0 if blur is None else float(blur), α, x, β, y)
+
+    # potentials (``:139-141``): rows of x, rows of y; each differentiates through its own rows only, with a doubled gradient
+    # (``:117-125`` plays the same trick on K_xx and K_yy); the columns and their weights are constants
     U_x = hip.kernel_conv(name, double_grad(x), z, w, blur)      # (k*α - k*β)(x_i)
     U_y = hip.kernel_conv(name, double_grad(y), z, w, blur)      # (k*α - k*β)(y_j)
-    if potentials:
-        return U_x, -U_y
-    return 0.5 * scal_sum(double_grad(α), U_x, double_grad(β), -U_y, batch=batch)
+    return U_x, -U_y
 
 
 def kernel_loss(

@@ -252,15 +252,23 @@ def test_kernel_norm_runs_on_the_union_cloud(monkeypatch):
         seen.append((kind, int(flags), x.requires_grad, tuple(x.shape), tuple(y.shape), v.detach().clone()))
         return (v.sum(-1, keepdim=True) + 0 * x.sum(-1)).expand(x.shape[:-1]) if v.dim() == x.dim() - 1 else v
 
+    units = []
+
+    def record_with_unit(kind, x, y, v, blur, want_unit, flags=0):      # the one-node path taken when a gradient is wanted
+        units.append(bool(want_unit))
+        return record(kind, x, y, v, blur, None, flags), None
+
     monkeypatch.setattr(hip, "kernel_conv", record)
+    monkeypatch.setattr(hip, "kernel_conv_with_unit", record_with_unit)
     x, y = torch.rand(7, 3), torch.rand(5, 3)
     a, b = torch.full((7,), 1 / 7), torch.full((5,), 1 / 5)
     for name in ("gaussian", "laplacian", "energy"):
         for grad in (False, True):
             seen.clear()
-            ks.kernel_online(a, x.clone().requires_grad_(grad), b, y, blur=0.1, name=name)
+            units.clear()
+            out = ks.kernel_online(a, x.clone().requires_grad_(grad), b, y, blur=0.1, name=name)
             assert [(s[3], s[4]) for s in seen] == [((7, 3), (12, 3)), ((5, 3), (12, 3))] and {s[1] for s in seen} == {0}
-            assert [s[2] for s in seen] == [grad, False]
+            assert units == ([True, False] if grad else []) and out.requires_grad == grad     # product + gradient in one pass for x only
             for s in seen:
                 assert torch.equal(s[5], torch.cat((a, -b)))
     seen.clear()                  # batches: the union along the point axis
@@ -313,6 +321,7 @@ def test_kernel_norm_value_only_launches(monkeypatch):
 
     sorted_clouds = []
     monkeypatch.setattr(hip, "kernel_conv", record)
+    monkeypatch.setattr(hip, "kernel_conv_with_unit", lambda kind, x, y, v, blur, want_unit, flags=0: (record(kind, x, y, v, blur, None, flags), None))
     monkeypatch.setattr(hip, "compact_order", lambda pts: (sorted_clouds.append(pts.shape[0]), (torch.arange(pts.shape[0]), pts))[1])
     monkeypatch.setattr(ks, "_UPPER_MIN_PAIRS", 0.0)
     x, y = torch.rand(300, 3), torch.rand(280, 3)

@@ -337,6 +337,49 @@ def test_kernel_norm_value_only_takes_the_upper_triangle(cuda, monkeypatch, name
     assert abs(L1.item() - ref1) < 1e-4 * abs(ref1) and abs(Lb[0].item() - ref1) < 1e-4 * abs(ref1), (L1.item(), Lb[0].item(), ref1)
 
 
+@pytest.mark.parametrize("batch", [False, True])
+def test_gaussian_second_order_derivatives(cuda, batch):
+    """create_graph=True: the gradient of the matrix-free gaussian norm is itself differentiable (KeOps' symbolic Grad composes,
+    _legacy/kernel_samples.py:43-54; here kernel_samples._UnionNorm.backward switches to differentiable kernel products) —
+    Hessian-vector products in x, mixed derivatives in (x, y) and in the weights, against the loss written with dense float64 torch
+    operations and NO detached copies: the derivatives of the loss itself (the reference's DoubleGrad trick is exact at first order
+    only: its Hessian of a self-term drops the dependence through the detached cloud).  The laplacian / energy norms and the
+    soft-min stay first-order: autograd raises when a second derivative is taken through them."""
+    g = torch.Generator().manual_seed(5)
+    shp = (3, 150, 3) if batch else (150, 3)
+    x = torch.rand(*shp, generator=g).to(cuda)
+    y = (torch.rand(*shp[:-2], 130, 3, generator=g) * 0.9).to(cuda)
+    a = torch.rand(*shp[:-1], generator=g).to(cuda) + 0.5
+    a = a / a.sum(-1, keepdim=True)
+    u = torch.randn(*shp, generator=g).to(cuda)
+    blur = 0.2
+
+    def dense(as_, xs, b, ys):
+        z, w = torch.cat((xs, ys), -2), torch.cat((as_, -b), -1)
+        K = (-((z.unsqueeze(-2) - z.unsqueeze(-3)) ** 2).sum(-1) / (2 * blur**2)).exp()
+        return 0.5 * (w.unsqueeze(-2) @ K @ w.unsqueeze(-1)).squeeze(-1).squeeze(-1)
+
+    def second_order(loss, dtype):
+        xs, ys, as_ = (t.to(dtype).clone().requires_grad_(True) for t in (x, y, a))
+        b = torch.full(ys.shape[:-1], 1.0 / ys.shape[-2], dtype=dtype, device=cuda)
+        L = loss(as_, xs, b, ys)
+        first = L.detach().clone()
+        (gx,) = torch.autograd.grad(L.sum(), [xs], create_graph=True)
+        hv, mixed, wa = torch.autograd.grad((gx * u.to(dtype)).sum(), [xs, ys, as_])
+        return first, gx.detach(), hv, mixed, wa
+
+    ref = second_order(dense, torch.float64)
+    got = second_order(SamplesLoss("gaussian", blur=blur, backend="online"), torch.float32)
+    for r, o, name in zip(ref, got, ("loss", "dL/dx", "H u", "d(dL/dx . u)/dy", "d(dL/dx . u)/da")):
+        assert relerr(o.cpu().numpy(), r.cpu().numpy()) < 1e-4, name
+    if not batch:
+        for loss in (SamplesLoss("energy", backend="online"), SamplesLoss("sinkhorn", blur=0.1, backend="online")):
+            xs = x.clone().requires_grad_(True)
+            (gx,) = torch.autograd.grad(loss(xs, y), [xs], create_graph=True)
+            with pytest.raises(RuntimeError, match="differentiate twice|once_differentiable|does not require grad"):
+                torch.autograd.grad(gx.sum(), [xs])
+
+
 def test_kernel_product_under_no_grad_skips_the_gradient_kernel(cuda):
     """autograd.Function reports needs_input_grad = True for a leaf that requires gradients even under no_grad; the product must
     then still come from the product kernel (same bits as for a plain tensor), not from the product-and-gradient kernel."""
