@@ -374,13 +374,23 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
         if cap > _RANGES_WORST_CASE_MAX:
             totals = torch.empty(2, dtype=torch.int32, device=dev)
             _check(lib.glhip_block_ranges_count(*head, slices_r.data_ptr(), slices_c.data_ptr(), totals.data_ptr(), _stream(rows)), lib)
-            cap = max(max(int(v) for v in totals.tolist()), 1)          # the one host round trip of the big case
+            counts = [int(v) for v in totals.tolist()]                   # the one host round trip of the big case
+            if min(counts) < 0:      # int32 totals: a kept pattern of >= 2^31 intervals wraps around
+                raise ValueError("geomloss_amd: the block-sparse pattern has more than 2^31 column intervals; use a larger cluster_scale.")
+            cap = max(max(counts), 1)
+            counted = True
+        else:
+            counted = False
         red_c = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         red_r = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-        status = torch.empty(1, dtype=torch.int32, device=dev)          # cannot fire: both capacities above always suffice
+        status = torch.zeros(1, dtype=torch.int32, device=dev)          # set by the kernel if an interval did not fit `cap`
         rc = lib.glhip_block_ranges(*head, slices_r.data_ptr(), red_c.data_ptr(), slices_c.data_ptr(), red_r.data_ptr(), cap,
                                     status.data_ptr(), _stream(rows))
     _check(rc, lib)
+    # worst-case buffers cannot overflow; counted ones could only if the two passes disagreed: the host is already in step with
+    # the stream there (it read the totals), so the check costs one more small read-back and nothing is dropped silently
+    if counted and int(status.item()) != 0:
+        raise RuntimeError("geomloss_amd: glhip_block_ranges wrote more intervals than its counting pass announced.")
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
 
@@ -485,6 +495,15 @@ class _CompactRows:
         return out
 
 
+def compact_rows_plan_applies(x, y, ranges=None, flags=0):
+    """Whether :func:`compact_rows_plan` would build a plan for these clouds (shapes and flags only: no device work)."""
+    B = 1 if x.dim() == 2 else x.shape[0]
+    N, M, D = x.shape[-2], y.shape[-2], x.shape[-1]
+    flags = int(flags) | ENV_FLAGS
+    return not (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS
+                or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT)))
+
+
 def compact_rows_plan(x, y, ranges=None, flags=0):
     """A :class:`_CompactRows` plan for the dense distance-type launches (p = 1 soft-min, laplacian / energy products) over the
     clouds x (N,D)|(1,N,D), y likewise, or None when such launches are too small to be worth the two voxel sorts.
@@ -499,11 +518,7 @@ def compact_rows_plan(x, y, ranges=None, flags=0):
     xb, yb = (xb.unsqueeze(0) if xb.dim() == 2 else xb), (yb.unsqueeze(0) if yb.dim() == 2 else yb)
     if yb.dtype != xb.dtype:
         yb = yb.to(xb.dtype)
-    B, N, D = xb.shape
-    M = yb.shape[1]
-    flags = int(flags) | ENV_FLAGS
-    if (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS
-            or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
+    if not compact_rows_plan_applies(xb, yb, ranges, flags):
         return None
     return _CompactRows(xb, yb)
 

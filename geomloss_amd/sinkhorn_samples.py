@@ -244,7 +244,10 @@ def sinkhorn_online(
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
 
     a_log, b_log = log_weights(a), log_weights(b)
-    if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3:
+    # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
+    # capture does not allow — and launches of that size gain nothing from a graph)
+    sorts = p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x))
+    if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3 and not sorts:
         f_aa, g_bb, g_ab, f_ba = _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias)
     else:
         f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(

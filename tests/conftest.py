@@ -25,7 +25,7 @@ def golden_cases(mid=False):
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
-        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_", "ot_")):
+        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_", "ot_", "reference_")):
             continue   # special cases, and the grid-path vectors of make_golden_images.py (tests/test_images_*.py)
         if name not in MID_SIZE:
             out.append(name)
@@ -56,3 +56,38 @@ def cuda():
 def relerr(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def reference_dirac_cases():
+    """The cases drawn by the reference's own hypothesis strategy for its ``test_correct_values_diracs`` (tests/golden/
+    make_golden_ot_diracs.py): dicts of NumPy arrays / scalars; absent keys mean None."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_diracs_ot.npz")
+    z = np.load(path, allow_pickle=False)
+    out = []
+    for i in range(int(z["count"])):
+        pre = f"c{i}_"
+        out.append({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+    return out
+
+
+def reference_accepts(got, want, atol, rtol=0.0):
+    """The acceptance rule of the reference's tests/check_ot_result.py:26-83 for un-batched results, on NumPy values:
+    got / want = dicts with value, plan, potential_a, potential_b, marginal_a, marginal_b.  Returns the names that fail."""
+    bad = []
+
+    def close(a, b, name, rt=rtol):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        if a.shape != b.shape or not np.allclose(a, b, atol=atol, rtol=rt, equal_nan=True):
+            bad.append(name)
+    close(got["value"], want["value"], "value")
+    close(got["plan"], want["plan"], "plan")
+    ma, mb = np.mean(got["potential_a"]), np.mean(got["potential_b"])
+    wa, wb = np.mean(want["potential_a"]), np.mean(want["potential_b"])
+    close(ma + mb, wa + wb, "sum(dual_potentials)", 0.0)
+    close(got["potential_a"] - ma, want["potential_a"] - wa, "potential_a")
+    close(got["potential_b"] - mb, want["potential_b"] - wb, "potential_b")
+    for k in ("marginal_a", "marginal_b"):       # check_approx_equal skips what the expected result leaves at None
+        if want.get(k) is not None:
+            close(got[k], want[k], k)
+    return bad

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, ot_golden_cases, relerr
+from conftest import load_golden, ot_golden_cases, reference_accepts, reference_dirac_cases, relerr
 from geomloss_amd import ot
 from oracle import oracle_ot
 
@@ -31,6 +31,27 @@ def test_ot_oracle_matches_reference(name):
             assert relerr(out[k], rec[k]) < 1e-9, k
     if "plan_rows" in rec:
         assert relerr(out["plan"][:5], rec["plan_rows"]) < 1e-9
+
+
+def test_reference_dirac_cases_pin_the_oracle():
+    """The 60 cases the reference's own ``test_correct_values_diracs`` draws (its hypothesis strategy, derandomized:
+    tests/golden/make_golden_ot_diracs.py) with the outputs of the reference's solver on them: (i) the reference passes its own
+    acceptance rule on its own cases — the stored closed forms and the stored outputs are consistent; (ii) the float64 oracle
+    reproduces the reference's outputs."""
+    cases = reference_dirac_cases()
+    assert len(cases) == 60 and {c["X_a"].shape[-1] for c in cases} == {1, 2, 3, 4, 5}
+    for c in cases:
+        want = {k[5:]: c[k] for k in c if k.startswith("want_")}
+        ref = {k[4:]: c[k] for k in c if k.startswith("ref_")}
+        assert reference_accepts(ref, want, float(c["atol"]), float(c["rtol"])) == []
+        out = oracle_ot.solve_sample(c["X_a"].astype(np.float64), c["X_b"].astype(np.float64), a=c.get("a"), b=c.get("b"),
+                                     reg=float(c["reg"]), max_iter=int(c["max_iter"]))
+        tol = 1e-9 if str(c["dtype"]) == "float64" else 2e-5       # half of the cases ran in float32 in the reference
+        scale = max(1.0, abs(float(c["ref_value"])))
+        assert abs(out["value"] - float(c["ref_value"])) <= tol * scale
+        assert np.abs(out["potential_a"] - c["ref_potential_a"]).max() <= tol * scale
+        # the reference's float32 plan exp((f + g - C) / reg) carries the cancellation its own strategy warns about (diracs.py:80-83)
+        assert np.abs(out["plan"] - c["ref_plan"]).max() <= (1e-6 if str(c["dtype"]) == "float64" else float(c["atol"]))
 
 
 def test_annealing_parameters():

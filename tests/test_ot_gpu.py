@@ -72,6 +72,42 @@ def test_correct_values_diracs(D, data, max_iter, reg, library, dtype, device, w
     check(res.potential_a - res.potential_b, 0.0, (1,))
 
 
+def test_reference_suite_dirac_cases(cuda):
+    """The reference's own ``tests/test_ot_solve_sample.py::test_correct_values_diracs`` cannot run here (no reference tree on the
+    GPU box): its 60 drawn cases travel instead (tests/golden/make_golden_ot_diracs.py: the reference's hypothesis strategy,
+    derandomized, with library / dtype / weights as drawn) and are replayed through ``geomloss_amd.ot.solve_sample`` under the
+    reference's own acceptance rule (tests/check_ot_result.py: atol = 1e-2, potentials up to the usual constant), plus agreement
+    with what the reference's solver returned on them."""
+    from conftest import reference_accepts, reference_dirac_cases
+    cases = reference_dirac_cases()
+    assert len(cases) == 60
+    for c in cases:
+        lib, dtype = str(c["library"]), str(c["dtype"])
+
+        def cast(v):
+            if v is None:
+                return None
+            v = np.asarray(v).astype(dtype)
+            return torch.from_numpy(v).to(cuda) if lib == "torch" else v
+        res = ot.solve_sample(cast(c["X_a"]), cast(c["X_b"]), a=cast(c.get("a")), b=cast(c.get("b")), reg=float(c["reg"]),
+                              max_iter=int(c["max_iter"]), method=str(c["method"]))
+        got = {}
+        for k in ("value", "plan", "potential_a", "potential_b", "marginal_a", "marginal_b"):
+            v = getattr(res, k)
+            if lib == "torch":
+                assert isinstance(v, torch.Tensor) and str(v.dtype) == "torch." + dtype
+                v = v.cpu().numpy()
+            else:
+                assert isinstance(v, np.ndarray) or np.isscalar(v)
+                assert str(np.asarray(v).dtype) == dtype
+            got[k] = v
+        want = {k[5:]: c[k] for k in c if k.startswith("want_")}
+        assert reference_accepts(got, want, float(c["atol"]), float(c["rtol"])) == []
+        scale = max(1.0, abs(float(c["ref_value"])))
+        assert abs(float(got["value"]) - float(c["ref_value"])) <= 1e-4 * scale
+        assert np.abs(np.asarray(got["potential_a"], np.float64) - c["ref_potential_a"]).max() <= 1e-4 * scale
+
+
 def test_correct_values_permutations(cuda):
     """Target = a shuffled copy of the source moved by a small, constant shift: at a small temperature the plan is the
     permutation matrix / N (the closed form behind generators/permutations.py), and value, plan and marginals agree with
