@@ -56,7 +56,7 @@ VALU_PEAK_PAIRS_PER_S = SIMDS * CLOCK_HZ * 64 / NOMINAL_CYCLES_PER_64_PAIRS
 # measured on this part (tools/ubench, profiles/r01_ubench_pipes.txt): that exp2 + add stream alone runs at 12.5
 # cycles per 64 pairs (v_exp_f32 8.2-9.7, v_add_f32 2.5-3.1), the kernel's bare inner loop (MFMA pair + stream) at 13.5
 MEASURED_STREAM_CYCLES = 12.5
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_softmin.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_softmin.json")
 
 
 def log(*a):

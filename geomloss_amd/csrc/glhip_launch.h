@@ -127,6 +127,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     sp.split_stride = (long)B * N * 2;
     sp.xcd_grid_x = 0;
     sp.xcd_blocks = 0;
+    // block-sparse: small row clusters come with short column intervals (the reference's cluster_scale rule makes ~2000 clusters
+    // whatever N is) — gather them into full tiles; clusters of hundreds of points already fill theirs
+    sp.gather = (n_ranges > 0 && N / n_ranges < 128) ? 1 : 0;
 
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.

@@ -33,6 +33,7 @@ struct SplitInfo {
     long split_stride;  // floats between consecutive splits = B*N*kPartial
     int xcd_grid_x;     // > 0: 1-D XCD-aware grid (see workgroup_coords); value = number of row blocks per batch item
     int xcd_blocks;     // XCD-aware grid: row blocks x batch items (workgroups per column split)
+    int gather = 0;     // block-sparse forward kernel: tiles gather several short column intervals (glhip_softmin_x32.h: gather_tile)
 };
 
 // Logical (row block, batch item, column split) of this workgroup.  Plain mode: the 3-D grid.  XCD-aware mode

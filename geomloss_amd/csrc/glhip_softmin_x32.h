@@ -173,13 +173,15 @@ __device__ __forceinline__ void open_interval(const Ranges& rg, int M, int q_end
 // points), and at N = 1e6 (455 columns per cluster, runs of 1-3 kept clusters) a third of the tiles were short tails.
 // gather_tile: the columns of slots t = tid + k * THREADS of the tile that starts at cursor c (-1: padding), the number of real
 // columns of the tile, and the cursor after it.  The walk over the intervals is wave-uniform (scalar loads and loop control).
+// `pieces`: how many interval pieces a tile may hold — 1 = one tile per piece (long intervals: the walk below would only delay
+// the prefetch; measured 1 % at N = 1e6), kTileX = gather freely (short intervals).  The host decides per launch (SplitInfo::gather).
 template <int K, int THREADS>
 __device__ __forceinline__ TileCursor gather_tile(const Ranges& rg, int M, int q_end, int split, int ns, TileCursor c, int tid,
-                                                  int (&cols)[K], int& n) {
+                                                  int (&cols)[K], int& n, int pieces) {
 #pragma unroll
     for (int k = 0; k < K; ++k) cols[k] = -1;
     int off = 0;
-    while (c.q < q_end && off < kTileX) {
+    while (c.q < q_end && off < kTileX && pieces-- > 0) {
         const int len = min(c.je - c.j0, kTileX - off);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -260,6 +262,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         cur.q = q_begin + (SPARSE ? split : 0);
         cur.j0 = cur.je = 0;
         open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, cur);
+        const int pieces = sp.gather ? kTileX : 1;
         constexpr bool GATHER = SPARSE && PRE;   // pre-packed: the gathered tile is fetched into registers one tile ahead
         constexpr bool GATHER_NOW = SPARSE && !PRE;   // packed on the fly: gathered when it is staged
         constexpr int kCols = kPer / 4;          // columns a thread moves per tile
@@ -275,7 +278,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         };
         if (GATHER) {
             if (cur.q < q_end) {
-                gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn);
+                gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
                 fetch_gathered();
             }
         } else if (PRE && cur.q < q_end) {
@@ -285,7 +288,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         while (cur.q < q_end) {
             {
                 const int j0 = cur.j0;
-                if (GATHER_NOW) gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn);
+                if (GATHER_NOW) gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
                 const int n = (GATHER || GATHER_NOW) ? gn : min(kTileX, cur.je - j0);
                 const int npad = (n + 31) & ~31;
                 TileCursor nxt = cur;   // the tile after this one
@@ -320,7 +323,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 }
                 if (GATHER) {
                     if (nxt.q < q_end) {
-                        gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, nxt, tid, gcols, gn);
+                        gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, nxt, tid, gcols, gn, pieces);
                         fetch_gathered();
                     }
                 } else if (PRE) {

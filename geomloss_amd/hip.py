@@ -71,7 +71,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("GEOMLOSS_HIP_LIB") or LIB_PATH      # GEOMLOSS_HIP_LIB: another build of the same C-ABI (A/B runs)
     if not os.path.exists(path):
         raise RuntimeError(
             f"geomloss_amd: the HIP extension {path} is missing. Build it with "
