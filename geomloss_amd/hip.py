@@ -60,10 +60,17 @@ SIGNATURES = {
                            + [ctypes.c_longlong, _vp, _vp]),
     "glhip_block_ranges_count": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 5 + [_vp]),
 }
+_c_double = ctypes.c_double
+SIGNATURES.update({
+    # float64 reductions (glhip_api_f64.hip): every array is double; no workspace, no flags
+    "glhip_softmin_fwd_f64": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_double, _c_int] + _RANGES + [_vp]),
+    "glhip_softmin_bwd_x_f64": (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_int, _c_int, _c_double, _c_int] + _RANGES + [_vp]),
+    "glhip_kernel_conv_fwd_f64": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_double] + _RANGES + [_vp]),
+    "glhip_kernel_conv_bwd_x_f64": (_c_int, [_c_int] + [_vp] * 5 + [_c_int, _c_int, _c_int, _c_int, _c_double] + _RANGES + [_vp]),
+})
 KEEP_DUAL_SLACK, KEEP_WITHIN = 0, 1
 
 _lib = None
-_warned = {"f64": False}
 
 
 def load_library(path=None):
@@ -105,19 +112,21 @@ def _stream(t):
 
 
 def _points(t, name):
-    """Point clouds go to the kernels as contiguous fp32 or bf16; other float types are widened/narrowed to fp32."""
+    """Point clouds go to the kernels as contiguous fp32, bf16 or fp64; other float types are widened / narrowed to fp32.
+    float64 clouds keep their dtype — the reference's matrix-free backends do (``_legacy/sinkhorn_samples.py:229-290``) — and run
+    on the double-precision kernels (``glhip_*_f64``: no matrix cores, ~20x slower than fp32; cast to fp32 for speed)."""
     if not t.is_cuda:
         raise RuntimeError(
             f"geomloss_amd: '{name}' lives on {t.device}; the HIP backends ('online', 'multiscale') need GPU tensors. "
             "Use backend='tensorized' for CPU tensors."
         )
-    if t.dtype not in (torch.float32, torch.bfloat16):
-        if t.dtype == torch.float64 and not _warned["f64"]:
-            _warned["f64"] = True
-            warnings.warn("geomloss_amd: the HIP kernels compute in fp32; float64 inputs are cast down "
-                          "(use backend='tensorized' for double precision).")
+    if t.dtype not in (torch.float32, torch.bfloat16, torch.float64):
         t = t.float()
     return t.contiguous()
+
+
+def is_f64(t):
+    return t.dtype == torch.float64
 
 
 def _dtype_code(t):
@@ -126,6 +135,16 @@ def _dtype_code(t):
 
 def _f32(t):
     return t.detach().float().contiguous()
+
+
+def _acc_dtype(points):
+    """dtype of dual vectors, weights, gradients and outputs next to clouds of this dtype: fp64 with fp64 clouds, fp32 otherwise."""
+    return torch.float64 if points.dtype == torch.float64 else torch.float32
+
+
+def _vec(t, points):
+    """A per-point vector (dual values, weights, gradients) in the accumulation dtype of the clouds it goes with."""
+    return t.detach().to(_acc_dtype(points)).contiguous()
 
 
 class BlockRanges:
@@ -171,7 +190,10 @@ def _workspace(lib, x, B, N, M, D, ranges):
 
 
 def _as_batched(x, y, s):
-    """(N,D),(M,D),(M,) -> (1,N,D),(1,M,D),(1,M); batched inputs pass through."""
+    """(N,D),(M,D),(M,) -> (1,N,D),(1,M,D),(1,M); batched inputs pass through.  The per-column vector follows the clouds' accumulation
+    dtype (fp64 next to fp64 clouds)."""
+    if s.dtype != _acc_dtype(x):
+        s = s.to(_acc_dtype(x))
     if x.dim() == 2:
         return x.unsqueeze(0), y.unsqueeze(0), s.reshape(1, -1), False
     return x, y, s.reshape(x.shape[0], -1), True
@@ -186,6 +208,13 @@ def softmin_fwd_raw(x, y, h, eps, p=2, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
+    if is_f64(x):
+        out = torch.empty((B, N), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.glhip_softmin_fwd_f64(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, D, float(eps), int(p),
+                                           *_range_args(ranges, B), _stream(x))
+        _check(rc, lib)
+        return out
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
@@ -240,6 +269,13 @@ def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
+    if is_f64(x):
+        gx = torch.empty((B, N, D), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.glhip_softmin_bwd_x_f64(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), grad_out.data_ptr(), gx.data_ptr(),
+                                             B, N, M, D, float(eps), int(p), *_range_args(ranges, B), _stream(x))
+        _check(rc, lib)
+        return gx
     gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
@@ -271,6 +307,13 @@ def kernel_conv_fwd_raw(kind, x, y, v, blur, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
+    if is_f64(x):
+        out = torch.empty((B, N), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.glhip_kernel_conv_fwd_f64(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), out.data_ptr(), B, N, M, D, float(blur),
+                                               *_range_args(ranges, B), _stream(x))
+        _check(rc, lib)
+        return out
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
@@ -285,6 +328,13 @@ def kernel_conv_bwd_x_raw(kind, x, y, v, g, blur, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
+    if is_f64(x):
+        gx = torch.empty((B, N, D), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.glhip_kernel_conv_bwd_x_f64(int(kind), x.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, M, D,
+                                                 float(blur), *_range_args(ranges, B), _stream(x))
+        _check(rc, lib)
+        return gx
     gx = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
@@ -500,7 +550,7 @@ def compact_rows_plan_applies(x, y, ranges=None, flags=0):
     B = 1 if x.dim() == 2 else x.shape[0]
     N, M, D = x.shape[-2], y.shape[-2], x.shape[-1]
     flags = int(flags) | ENV_FLAGS
-    return not (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS
+    return not (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS or is_f64(x)
                 or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT)))
 
 
@@ -541,10 +591,10 @@ class _Softmin(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, h, eps, p, ranges, flags, plan=None):
-        xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(h))
+        xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), h.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        plan = _plan_for(plan, xb, yb, ranges, flags) if p == 1 else None
+        plan = _plan_for(plan, xb, yb, ranges, flags) if (p == 1 and not is_f64(xb)) else None
         if plan is not None:       # large dense p = 1 launch: voxel-sorted clouds, squared distances on the matrix cores
             out = plan.unsort(softmin_fwd_raw(plan.x, plan.y, plan.cols(hb), eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
         else:
@@ -565,7 +615,7 @@ class _Softmin(torch.autograd.Function):
             )
         xb, yb, hb, out = ctx.saved_tensors
         eps, p, ranges, flags, xshape, xdtype = ctx.cfg
-        g = grad_out.reshape(out.shape).float().contiguous()
+        g = grad_out.reshape(out.shape).to(out.dtype).contiguous()
         gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
         return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None, None
 
@@ -599,7 +649,8 @@ def softmin_value_and_grad(eps, x, y, h, guess, margin, ranges=None, flags=0):
     """``softmin(eps, x, y, h)`` (differentiable in x) from one reduction instead of a forward and a backward one, or None when that
     does not apply: x needs no gradient, p = 2 / D <= 16 kernels only, launches too small to pay for the host check of ``margin``
     (a device scalar: sup |h - h_previous| * eps), or a margin beyond 25 eps (the loop has not converged: use the two passes)."""
-    if not (torch.is_grad_enabled() and x.requires_grad) or x.shape[-1] > XD_MAX_DIM or (int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT):
+    if (not (torch.is_grad_enabled() and x.requires_grad) or x.shape[-1] > XD_MAX_DIM or is_f64(x)
+            or (int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT)):
         return None
     rows, cols = x.shape[-2], y.shape[-2]
     B = 1 if x.dim() == 2 else x.shape[0]
@@ -767,11 +818,11 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); logw, pot: (M,)|(B,M) (pot may be None); prev: (N,)|(B,N) or None.
     Returns fp32 (N,)|(B,N).  Used by the drivers inside the no-grad part of ``sinkhorn_loop``."""
-    if not fused_step_applies(x.shape[-1], p, flags):
+    if not fused_step_applies(x.shape[-1], p, flags) or is_f64(x):      # (float64 clouds: the double-precision kernels have no fused form)
         with torch.no_grad():
-            h = _f32(logw) if pot is None else _f32(logw) + _f32(pot).reshape(logw.shape) / eps
+            h = _vec(logw, x) if pot is None else _vec(logw, x) + _vec(pot, x).reshape(logw.shape) / eps
             ft = damping * softmin(eps, x.detach(), y.detach(), h, p=p, ranges=ranges, flags=flags, plan=plan)
-            return ft if prev is None else 0.5 * (_f32(prev).reshape(ft.shape) + ft)
+            return ft if prev is None else 0.5 * (_vec(prev, x).reshape(ft.shape) + ft)
     xb, yb, lw, batched = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(logw))
     if yb.dtype != xb.dtype:
         yb = yb.to(xb.dtype)
@@ -802,7 +853,7 @@ _GAUSS_SORT_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_GAUSS_SORT_MIN", "1e1
 def _gauss_compact_rows(kind, xb, M, ranges, flags):
     """(perm, rows in compact order) for a big dense gaussian launch of the per-workgroup-centre kernels, or None."""
     B, N, D = xb.shape
-    if (kind != GAUSSIAN or ranges is not None or B != 1 or D > 3 or float(N) * M < _GAUSS_SORT_MIN_PAIRS
+    if (kind != GAUSSIAN or ranges is not None or B != 1 or D > 3 or is_f64(xb) or float(N) * M < _GAUSS_SORT_MIN_PAIRS
             or (flags & (FLAG_NO_MFMA | FLAG_DIRECT))):
         return None
     perm, xs = compact_order(xb[0])
@@ -832,9 +883,11 @@ class _KernelConv(torch.autograd.Function):
     def product(kind, x, y, v, blur, ranges, flags, want_unit):
         """The launch behind forward: (xb, yb, vb, batched, out (B,N), unit (B,N,D) | None); unit_i = d out_i / d x_i when
         ``want_unit`` and a product-and-gradient kernel exists for this kind and dimension."""
-        xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
+        xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), v.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
+        if is_f64(xb):      # double precision: the plain product kernel, no plans, no fused gradient
+            return xb, yb, vb, batched, kernel_conv_fwd_raw(kind, xb, yb, vb, blur, ranges, flags), None
         # When x requires gradients, the product and its row gradient come out of ONE reduction: the gradient kernel
         # carries one more accumulator, the product itself.  The backward pass is then elementwise.
         # (D <= 3: every kernel; 4 <= D <= 16: the gaussian kernel on the matrix cores)
@@ -907,7 +960,7 @@ class _KernelConv(torch.autograd.Function):
     def _backward_once(ctx, grad_out):
         xb, yb, vb = ctx.saved_tensors[:3]
         kind, blur, ranges, flags, xs, ys, vs, xdt, ydt, vdt = ctx.cfg
-        g = grad_out.reshape(xb.shape[0], -1).float().contiguous()
+        g = grad_out.reshape(xb.shape[0], -1).to(vb.dtype).contiguous()
         rt = None if ranges is None else ranges.t()
         gx = gy = gv = None
         if ctx.needs_input_grad[1]:
@@ -972,10 +1025,10 @@ def kernel_conv_row_gradient(kind, x, y, v, g, blur, flags=0):
     """No autograd: d/dx of sum_i g_i (K v)_i as one gradient reduction (``glhip_kernel_conv_bwd_x``), shaped like x."""
     kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
     with torch.no_grad():
-        xb, yb, vb, _ = _as_batched(_points(x, "x"), _points(y, "y"), _f32(v))
+        xb, yb, vb, _ = _as_batched(_points(x, "x"), _points(y, "y"), v.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        gb = _f32(g).reshape(xb.shape[0], -1)
+        gb = _vec(g, xb).reshape(xb.shape[0], -1)
         return _KernelConv._row_gradient(kind, xb, yb, vb, gb, 1.0 if blur is None else float(blur), None, int(flags) | ENV_FLAGS).reshape(x.shape)
 
 

@@ -174,7 +174,12 @@ def _takes_no_gradient(*tensors):
 def _upper_triangle_applies(name, pts):
     """One un-batched cloud of dimension <= 3, big enough for the two block-sparse launches to pay."""
     return (name in _UPPER_KERNELS and pts.shape[-1] <= 3 and float(pts.shape[-2]) ** 2 >= _UPPER_MIN_PAIRS
-            and (pts.dim() == 2 or pts.shape[0] == 1))
+            and (pts.dim() == 2 or pts.shape[0] == 1) and pts.dtype != torch.float64)      # (the compact order is an fp32 / bf16 kernel)
+
+
+def _weights_dtype(points):
+    """Weights, products and sums are fp32 next to fp32 / bf16 / fp16 clouds, fp64 next to fp64 ones."""
+    return torch.float64 if points.dtype == torch.float64 else torch.float32
 
 
 class _UnionNorm(torch.autograd.Function):
@@ -192,7 +197,7 @@ class _UnionNorm(torch.autograd.Function):
     def forward(ctx, name, blur, α, x, β, y):
         batch = x.dim() > 2
         z = torch.cat((x, y.to(x.dtype)), dim=-2)
-        w = torch.cat((α.float(), -β.float()), dim=-1)
+        w = torch.cat((α.to(_weights_dtype(x)), -β.to(_weights_dtype(x))), dim=-1)
         U_x, unit_x = hip.kernel_conv_with_unit(name, x, z, w, blur, ctx.needs_input_grad[3])
         U_y, unit_y = hip.kernel_conv_with_unit(name, y, z, w, blur, ctx.needs_input_grad[5])
         ctx.name, ctx.blur, ctx.units = name, blur, (unit_x, unit_y)
@@ -218,10 +223,10 @@ class _UnionNorm(torch.autograd.Function):
             gβ = (-gl * U_y).to(β.dtype).reshape(β.shape)
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
             z = torch.cat((x, y.to(x.dtype)), dim=-2)
-            w = torch.cat((α.float(), -β.float()), dim=-1)
+            w = torch.cat((α.to(_weights_dtype(x)), -β.to(_weights_dtype(x))), dim=-1)
 
             def rows(pts, wt, unit):     # d/d pts_i of 1/2 <w, K w> = wt_i d U_i / d pts_i
-                g = gl * wt.float()
+                g = gl * wt.to(w.dtype)
                 if unit is not None:
                     return (g.unsqueeze(-1) * unit).to(pts.dtype).reshape(pts.shape)
                 return hip.kernel_conv_row_gradient(name, pts, z, w, g, blur).to(pts.dtype)
@@ -260,7 +265,7 @@ def _kernel_loss_union(α, x, β, y, blur, name, potentials):
         raise KeyError(name)
     batch = x.dim() > 2
     z = torch.cat((x.detach(), y.detach().to(x.dtype)), dim=-2)
-    w = torch.cat((α.detach().float(), -β.detach().float()), dim=-1)
+    w = torch.cat((α.detach().to(_weights_dtype(x)), -β.detach().to(_weights_dtype(x))), dim=-1)
 
     if not potentials and _takes_no_gradient(α, x, β, y) and _upper_triangle_applies(name, z):
         out = (0.5 * _quadratic_form_value(name, z, w, blur)).float()

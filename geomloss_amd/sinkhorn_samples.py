@@ -170,7 +170,7 @@ class _HipSoftmin:
         on its own (those run faster as separate launches with pre-packed columns).  The coarse level of the multiscale
         backend (dense, ~2e3 clusters with their own weights) qualifies: its 7 x 4 soft-mins become 7 launches."""
         x, y = C_xy[0], C_xy[1]
-        if self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations:
+        if self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations or x.dtype == torch.float64:
             return None
         if self.multiscale and C_xy[4] is not None:     # truncated fine level: block-sparse launches
             return None
@@ -247,7 +247,7 @@ def sinkhorn_online(
     # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
     # capture does not allow — and launches of that size gain nothing from a graph)
     sorts = p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x))
-    if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3 and not sorts:
+    if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3 and not sorts and x.dtype != torch.float64:
         f_aa, g_bb, g_ab, f_ba = _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias)
     else:
         f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(

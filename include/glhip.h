@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 108 /* 0.1.8 */
+#define GLHIP_VERSION 109 /* 0.1.9 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -324,6 +324,27 @@ int glhip_block_ranges(int kind, const float* rows, const float* cols, const flo
 int glhip_block_ranges_count(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
                              int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
                              int32_t* slices_rows, int32_t* slices_cols, int32_t* totals, void* stream);
+
+/* ---- the four reductions in DOUBLE precision (round 4) ---------------------------------------------------------------------
+ * The reference's matrix-free backends keep the dtype of their inputs: float64 clouds are reduced in float64 by KeOps
+ * (softmin_online_lazytensor, sinkhorn_samples.py:229-290, `.logsumexp` on LazyTensors of the input dtype; lse_genred :322-334
+ * with dtype = float64; kernel_online, kernel_samples.py:128-137).  These entry points are that path: every array — clouds, dual
+ * vector / weights, gradients, outputs — is `double`; same argument meaning, ranges convention and semantics (clamp of
+ * utils.py:61, zero direction at clamped pairs) as glhip_softmin_fwd / glhip_softmin_bwd_x / glhip_kernel_conv_fwd /
+ * glhip_kernel_conv_bwd_x above; 1 <= D <= 16 (GLHIP_EUNSUPPORTED beyond); no workspace, no flags.  One thread per row,
+ * explicit differences, no matrix cores: ~4e11 pairs/s, for callers who need the digits.  The fused entry points (half-step,
+ * iteration, value + gradient) have no float64 form: compose these. */
+int glhip_softmin_fwd_f64(const double* x, const double* y, const double* h, double* out, int B, int N, int M, int D, double eps, int p,
+                          const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* stream);
+int glhip_softmin_bwd_x_f64(const double* x, const double* y, const double* h, const double* out, const double* grad_out, double* grad_x,
+                            int B, int N, int M, int D, double eps, int p, const int32_t* ranges_i, const int32_t* slices_i,
+                            const int32_t* redranges_j, int n_ranges, void* stream);
+int glhip_kernel_conv_fwd_f64(int kind, const double* x, const double* y, const double* v, double* out, int B, int N, int M, int D,
+                              double blur, const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges,
+                              void* stream);
+int glhip_kernel_conv_bwd_x_f64(int kind, const double* x, const double* y, const double* v, const double* grad_out, double* grad_x, int B,
+                                int N, int M, int D, double blur, const int32_t* ranges_i, const int32_t* slices_i,
+                                const int32_t* redranges_j, int n_ranges, void* stream);
 #ifdef __cplusplus
 }
 #endif
