@@ -207,14 +207,20 @@ def hot_path_kernels(dev, n=1_000_000):
     add("laplacian_product", fresh(lambda: hip.kernel_conv("laplacian", x2, y2, v1, blur)), reps=2)
     add("energy_product", fresh(lambda: hip.kernel_conv("energy", x2, y2, v1, blur)), reps=2)
     add("softmin_fwd_p1_direct_differences", lambda: hip.softmin_fwd_raw(x, y, h, 0.05, 1), reps=1)
-    # 4 <= D <= 16: the same bf16x3 exponent as a chain of ceil((D + 1) / 2) MFMAs (csrc/glhip_softmin_xd.h)
+    # 4 <= D <= 16: the same bf16x3 exponent as a chain of ceil(6 (D + 1) / 16) MFMAs (csrc/glhip_softmin_xd.h)
     gd = torch.Generator().manual_seed(11)
-    for D in (4, 5, 8, 16):
+    for D in (4, 5, 8, 12, 16):
         xd = torch.rand(1, n, D, generator=gd).to(dev)
         yd = torch.rand(1, n, D, generator=gd).to(dev)
         add(f"softmin_fwd_p2_d{D}", lambda: hip.softmin_fwd_raw(xd, yd, h, eps, 2), reps=2)
         if D == 4:
             add("gaussian_product_d4", lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, xd, yd, v, 2 * blur), reps=2)
+    # float64 clouds (csrc/glhip_api_f64.hip): one thread per row, no matrix cores — timed on a tenth of the rows
+    m = max(n // 10, 1)
+    x64, y64, h64 = x[:, :m].double().contiguous(), y.double(), h.double()
+    ms = event_ms(lambda: hip.softmin_fwd_raw(x64, y64, h64, eps, 2), 1)
+    res["softmin_fwd_p2_f64"] = {"ms": ms, "rows": m, "pairs_per_s": float(m) * n / (ms * 1e-3)}
+    log(f"[bench] softmin_fwd_p2_f64 ({m} rows x {n} columns): {ms:.2f} ms  {float(m) * n / ms * 1e3:.3e} pairs/s")
     return res
 
 
