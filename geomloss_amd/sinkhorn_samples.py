@@ -172,6 +172,8 @@ class _HipSoftmin:
         x, y = C_xy[0], C_xy[1]
         if self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations or x.dtype == torch.float64:
             return None
+        if hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16):
+            return None     # the one-launch iteration exists on the default kernel only: a kernel-selection flag means "not that one"
         if self.multiscale and C_xy[4] is not None:     # truncated fine level: block-sparse launches
             return None
         B = 1 if x.dim() == 2 else x.shape[0]

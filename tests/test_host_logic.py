@@ -385,6 +385,15 @@ def test_fused_half_step_dispatch_follows_the_flags(monkeypatch):
     monkeypatch.setattr(hip, "ENV_FLAGS", 0)
     assert not hip.fused_step_applies(5, 2, flags=hip.FLAG_NO_MFMA) and hip.fused_step_applies(3, 2, flags=hip.FLAG_NO_MFMA)
 
+    # the one-launch iteration (glhip_sinkhorn_iter4) runs the default kernel only: any kernel-selection flag switches it off
+    from geomloss_amd import sinkhorn_samples as ss0
+    monkeypatch.setattr(hip, "Iter4Plan", lambda *a, **k: "plan")
+    x3, al = torch.rand(7, 3), torch.zeros(7)
+    for env, want in ((0, "plan"), (hip.FLAG_NO_SPLIT, "plan"), (hip.FLAG_NO_MFMA, None), (hip.FLAG_DIRECT, None), (hip.FLAG_XDL16, None),
+                      (hip.FLAG_F32_MFMA, None)):
+        monkeypatch.setattr(hip, "ENV_FLAGS", env)
+        assert ss0._HipSoftmin(2, multiscale=False)._iter4_plan((x3, x3), al, al, True, create=True) == want, env
+    monkeypatch.setattr(hip, "ENV_FLAGS", 0)
     # the drivers: _HipSoftmin.step and ot._averaged compose soft-min + arithmetic instead of calling the fused entry point
     from geomloss_amd import sinkhorn_samples as ss
     from geomloss_amd.ot import sinkhorn_ot
