@@ -1,4 +1,4 @@
-"""GPU box: two launches each of the D = 5, 8, 16 soft-min forward and the D = 8 gaussian product at N = M = 1e6 (glhip_softmin_xd.h),
+"""GPU box: two launches each of the D = 4, 8, 12, 16 soft-min forward and the D = 8 gaussian product at N = M = 1e6 (glhip_softmin_xd.h),
 the workload rocprofv3 is pointed at by tools/profile_kernels.sh <tag> kernels_xd_1e6.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ from geomloss_amd import hip
 
 dev = torch.device("cuda:0")
 n = 1_000_000
-for D in (5, 8, 16):
+for D in (4, 8, 12, 16):
     g = torch.Generator().manual_seed(D)
     x = torch.rand(1, n, D, generator=g).to(dev)
     y = torch.rand(1, n, D, generator=g).to(dev)

@@ -9,6 +9,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/t
 timeout 300 rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace -d $OUT/pmc_util -o pmc -- $CMD > $OUT/pmc_util.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_inst -o pmc -- $CMD > $OUT/pmc_inst.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_wait -o pmc -- $CMD > $OUT/pmc_wait.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_pipe -o pmc -- $CMD > $OUT/pmc_pipe.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 cd $REPO
@@ -21,7 +22,7 @@ for db in glob.glob("$OUT/trace/**/*.db", recursive=True):
     for r in list(c.execute("select name, total_calls, average, percentage from top_kernels"))[:16]:
         print(f"{r[1]:5d}  {r[2]:12.1f}  {r[3]:6.2f}%  {r[0][:140]}")
 vals = collections.defaultdict(dict)
-for sub in ("pmc_util", "pmc_inst", "pmc_wait", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_util", "pmc_inst", "pmc_wait", "pmc_pipe", "pmc_fetch", "pmc_write"):
     for db in glob.glob("$OUT/" + sub + "/**/*.db", recursive=True):
         c = sqlite3.connect(db)
         for k, cn, n, avg, dur in c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"):
@@ -35,6 +36,8 @@ for k, d in sorted(vals.items(), key=lambda kv: -kv[1]["_ns"]):
         line += f"  | VALU wave-instr per 64 pairs = {d['SQ_INSTS_VALU'] / (1e12 / 64):.2f}"
     if "GRBM_GUI_ACTIVE" in d:
         line += f"  clock = {d['GRBM_GUI_ACTIVE'] / 8.0 / d['_ns']:.2f} GHz"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+        line += f"  MFMA-busy cycles that co-execute with VALU = {d['SQ_VALU_MFMA_COEXEC_CYCLES'] / d['SQ_VALU_MFMA_BUSY_CYCLES']:.2f}"
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         line += f"  HBM bytes <= {(2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024 / 1e6:.0f} MB"
     print(line); print("            ", k[:160])
