@@ -48,7 +48,11 @@ struct Scratch {
     ChunkBuf cb;        // block-sparse launches: room for the row-chunk table, carved off the front of the workspace
     // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
     // GLHIP_FLAG_NO_SPLIT tells us to leave alone
-    bool prepack(double pairs) const { return ws && (force_pre || (allow_split && pairs >= 5e8)); }
+    bool prepack(double pairs) const { return ws && (force_pre || (allow_split && pairs >= prepack_min_pairs())); }
+    static double prepack_min_pairs() {     // tuning knob: GLHIP_PREPACK_MIN (pairs per launch)
+        static const double v = getenv("GLHIP_PREPACK_MIN") ? atof(getenv("GLHIP_PREPACK_MIN")) : 5e8;
+        return v;
+    }
 };
 
 // Scratch of one API call.  Block-sparse calls reserve the front of the workspace for the row-chunk table (sized for the

@@ -223,6 +223,10 @@ merge_kernel(typename Op::Params prm, Ranges rg, int N, SplitInfo sp) {
 
 // Number of column splits: enough workgroups for >= ~16 rounds over the chip.
 static inline int choose_splits(long row_blocks, int M, int n_ranges, long max_by_workspace) {
+    // dense launches that already fill the chip four times over gain nothing from splits and pay one prologue / epilogue / merge share
+    // per split: B = 256 x 4096 x 4096 (4096 row blocks, 3 splits by the rule below): 17.4 -> 15.9 ms per loss without (round 4)
+    // (short column loops only: with long ones the last partial round of long-lived workgroups is what splits are for)
+    if (n_ranges == 0 && row_blocks >= 4L * 768 && M <= 16384) return 1;
     const long target = 256L * 4 * 10;   // ~10 rounds of 4 workgroups per CU
     long ns = (target + row_blocks - 1) / row_blocks;
     const long by_cols = (n_ranges > 0) ? 8 : (long)M / 512;   // at least 512 columns per split
