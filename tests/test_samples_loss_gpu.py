@@ -380,6 +380,47 @@ def test_gaussian_second_order_derivatives(cuda, batch):
                 torch.autograd.grad(gx.sum(), [xs])
 
 
+@pytest.mark.parametrize("name", ["gaussian", "laplacian", "energy"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kernel_norms_half_precision_clouds_batched(cuda, name, dtype):
+    """bf16 / fp16 clouds in a batch, weights that take gradients, very different cloud sizes (M = 1 included): the union-cloud
+    norm against the float64 oracle evaluated on the ROUNDED points (the kernels read the half-precision values, accumulate fp32)."""
+    from oracle import oracle_torch64 as o64
+    g = torch.Generator().manual_seed(9)
+    for B, N, M in ((3, 300, 170), (2, 257, 1)):
+        x = torch.rand(B, N, 3, generator=g).to(cuda).to(dtype)
+        y = (torch.rand(B, M, 3, generator=g) * 0.7 + 0.2).to(cuda).to(dtype)
+        a = torch.rand(B, N, generator=g).to(cuda) + 0.2
+        a = (a / a.sum(-1, keepdim=True)).requires_grad_(True)
+        b = torch.full((B, M), 1.0 / M, device=cuda)
+        xg = x.clone().requires_grad_(True)
+        L = SamplesLoss(name, blur=0.2, backend="online")(a, xg, b, y)
+        assert L.shape == (B,) and L.dtype == torch.float32
+        gx, ga = torch.autograd.grad(L.sum(), [xg, a])
+        assert gx.dtype == dtype and ga.dtype == torch.float32
+        for k in range(B):
+            ref, rgx, rga = o64.kernel_loss(name, x[k].float(), y[k].float(), a[k].detach(), b[k], blur=0.2, grad=True, device=cuda)
+            assert abs(L[k].item() - ref) < 1e-4 * abs(ref), (name, dtype, k)
+            assert relerr(ga[k].cpu().numpy(), rga) < 1e-4
+            assert relerr(gx[k].float().cpu().numpy(), rgx) < (1e-2 if dtype == torch.bfloat16 else 2e-3)      # the gradient itself is rounded to bf16 / fp16
+
+
+def test_kernel_norm_is_symmetric_and_translation_invariant(cuda):
+    """L(a, x, b, y) = L(b, y, a, x) and L(x + t, y + t) = L(x, y): properties of the norm that the union-cloud evaluation keeps to
+    rounding (1e5 points: the matrix-free kernels; value only -> upper triangle of the union, with gradients -> two row passes)."""
+    g = torch.Generator().manual_seed(12)
+    N, M = 60_000, 50_000
+    x, y = torch.rand(N, 3, generator=g).to(cuda), (torch.rand(M, 3, generator=g) * 0.9).to(cuda)
+    t = torch.tensor([10.0, -7.0, 3.0], device=cuda)
+    for name in ("gaussian", "energy"):
+        loss = SamplesLoss(name, blur=0.1, backend="online")
+        L = loss(x, y).item()
+        assert abs(loss(y, x).item() - L) < 2e-5 * abs(L)
+        assert abs(loss(x + t, y + t).item() - L) < 2e-4 * abs(L)          # fp32 coordinates at +10 carry 1e-6 of absolute rounding
+        xg = x.clone().requires_grad_(True)
+        assert abs(loss(xg, y).item() - L) < 2e-5 * abs(L)
+
+
 def test_kernel_product_under_no_grad_skips_the_gradient_kernel(cuda):
     """autograd.Function reports needs_input_grad = True for a leaf that requires gradients even under no_grad; the product must
     then still come from the product kernel (same bits as for a plain tensor), not from the product-and-gradient kernel."""
