@@ -85,6 +85,34 @@ __device__ __forceinline__ uint32_t xd_slot(int slot, const uint32_t (&sc)[3], c
     return cp[d][piece];
 }
 
+// The same from the float values themselves, splitting what the record needs when it needs it (a record touches the scalar and
+// at most three coordinates): for the row pass of the kernels, where 3 (D + 1) live piece registers next to RT x NM finished
+// operands pushed D = 16 over 128 VGPRs.
+template <int D, bool XSIDE>
+__device__ __forceinline__ uint4 xd_record_of(int r, float scalar, const float (&val)[D]) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int slot = 8 * r + k;
+        uint32_t h = 0u;
+        if (slot < 6 * (D + 1)) {
+            uint32_t p[3];
+            if (slot < 6) {
+                const bool one = XSIDE ? slot < 3 : slot >= 3;
+                if (one) h = kBf16One;
+                else { split3_rn(scalar, p); h = p[XSIDE ? slot - 3 : slot]; }
+            } else {
+                const int d = (slot - 6) / 6, t = (slot - 6) % 6;
+                const int piece = XSIDE ? (t == 2 ? 1 : (t == 4 ? 2 : (t == 5 ? 1 : 0))) : (t == 1 ? 1 : (t == 3 ? 2 : (t == 5 ? 1 : 0)));
+                split3_rn(val[d < D ? d : 0], p);
+                h = p[piece];
+            }
+        }
+        w[k >> 1] |= (k & 1) ? (h << 16) : h;
+    }
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+
 // record r (slots 8 r .. 8 r + 7) of a column / a row
 template <int D, bool XSIDE>
 __device__ __forceinline__ uint4 xd_record(int r, const uint32_t (&sc)[3], const uint32_t (&cp)[D][3]) {
@@ -129,12 +157,8 @@ __device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long
             vj = prm.h[col];
         }
     }
-    uint32_t sc[3], cp[D][3];
-    split3_rn(H, sc);
 #pragma unroll
-    for (int d = 0; d < D; ++d) split3_rn(yt[d], cp[d]);
-#pragma unroll
-    for (int r = 0; r < S::NBP; ++r) base[r * stride] = xd_record<D, false>(r, sc, cp);
+    for (int r = 0; r < S::NBP; ++r) base[r * stride] = xd_record_of<D, false>(r, H, yt);      // record by record: few live pieces
     if (MODE == XD_GAUSS) *vdst = vj;
 }
 
@@ -244,13 +268,10 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
             }
             // scalar item of the x side: [1,1,1,n1,n2,n3]; soft-min: n = -running max (0 until the first group has been seen),
             // gaussian: n = r_i = -s/2 |xt_i|^2, constant
-            uint32_t sc[3], cp[D][3];
-            split3_rn((MODE == XD_SOFTMIN) ? 0.f : -0.5f * prm.s2 * n2, sc);
-#pragma unroll
-            for (int d = 0; d < D; ++d) split3_rn(a[d], cp[d]);
+            const float nrow = (MODE == XD_SOFTMIN) ? 0.f : -0.5f * prm.s2 * n2;
 #pragma unroll
             for (int mm = 0; mm < NM; ++mm)     // this lane's half of MFMA mm: record 2 mm + half
-                X[rt][mm] = select_u4(half != 0, xd_record<D, true>(2 * mm + 1, sc, cp), xd_record<D, true>(2 * mm, sc, cp));
+                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true>(2 * mm + 1, nrow, a), xd_record_of<D, true>(2 * mm, nrow, a));
             m[rt] = kMinusHuge;
             ssum[rt] = 0.f;
         }

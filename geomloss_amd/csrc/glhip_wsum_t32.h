@@ -24,12 +24,12 @@
 namespace glhip {
 
 template <int D>
-struct T32Shape {      // XdShape without its D >= 4 restriction
-    static constexpr int NB = D + 1;
-    static constexpr int NM = (NB + 1) / 2;
+struct T32Shape {      // the 6-slot K layout of XdShape (glhip_softmin_xd.h) without its D >= 4 restriction
+    static constexpr int NM = (6 * (D + 1) + 15) / 16;
     static constexpr int NBP = 2 * NM;
-    static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);
-    static constexpr int HM = D / 2, HH = D % 2;
+    // columns per LDS tile: (16 NBP + 4 (D + 1)) bytes each; 256 keeps four 4-wave workgroups (RT = 2) per CU up to NBP = 6
+    // (512 left two: LDS-bound occupancy of 2 waves per SIMD for D = 5 .. 7)
+    static constexpr int kTile = NBP <= 10 ? 256 : 128;
 };
 
 template <int MODE, int D>
@@ -39,7 +39,8 @@ struct T32Q {           // components of q_j kept in LDS, accumulators per row
 };
 
 template <int MODE, int D, typename T, bool SPARSE, int RT, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 4)      // <= 128 VGPRs: two 8-wave (four 4-wave) workgroups per CU; without the bound the
+                                                    // record assembly of the row pass pushes D = 16 to 131 VGPRs = one workgroup per CU (2x slower)
 wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     using S = T32Shape<D>;
     constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
@@ -66,7 +67,6 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
     block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const uint4 kZero = uint4{0u, 0u, 0u, 0u};
 
     for (int row0 = row_begin; row0 < row_end; row0 += kRowsPerBlock) {
         float centre[D];
@@ -92,17 +92,9 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
             //   C_i = r_i - LSE2_i, LSE2_i = fwd_i / out_scale (+ tscale: value-and-gradient mode, `fwd` is a guess and tscale the margin)
             float cst = -0.5f * prm.s2 * n2;
             if (MODE == WS_SOFTMIN_BWD) cst -= prm.fwd[(long)b * N + i] / prm.out_scale + prm.tscale;
-            const uint4 hblk = pack_negmax(-cst);      // [1,1,1,c1,c2,c3,0,0]
 #pragma unroll
-            for (int mm = 0; mm < NM; ++mm) {
-                const int kb0 = 2 * mm, kb1 = 2 * mm + 1;
-                const float av = (kb1 < D) ? (half ? a[kb1 < D ? kb1 : 0] : a[kb0]) : a[kb0 < D ? kb0 : 0];
-                uint4 pa = pack_a(av);
-                if (kb0 == D) pa = hblk;
-                if (kb1 == D) pa = select_u4(half != 0, hblk, pa);
-                if (kb1 > D) pa = select_u4(half != 0, kZero, pa);
-                X[rt][mm] = pa;
-            }
+            for (int mm = 0; mm < NM; ++mm)     // scalar item [1,1,1,c1,c2,c3] with c = cst, then six slots per coordinate (xd_record_of)
+                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true>(2 * mm + 1, cst, a), xd_record_of<D, true>(2 * mm, cst, a));
 #pragma unroll
             for (int c = 0; c < NA; ++c) acc[rt][c] = 0.f;
         }
@@ -133,9 +125,7 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     }
                     uint4* base = &tile[(t >> 5) * (32 * NBP) + (t & 31)];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) base[d * 32] = pack_y(yt[d]);
-                    base[D * 32] = pack_h1(H);
-                    if (NBP > S::NB) base[S::NB * 32] = kZero;
+                    for (int r = 0; r < NBP; ++r) base[r * 32] = xd_record_of<D, false>(r, H, yt);     // record by record: few live pieces
 #pragma unroll
                     for (int d = 0; d < D; ++d) tileQ[d * kTileD + t] = (MODE == WS_SOFTMIN_BWD) ? yt[d] : sj * yt[d];
                     if (MODE != WS_SOFTMIN_BWD) tileQ[D * kTileD + t] = (t < n) ? sj : 0.f;

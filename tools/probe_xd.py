@@ -31,7 +31,14 @@ for D in dims:
     y = torch.rand(1, n, D, generator=g).to(dev)
     h = (torch.randn(1, n, generator=g) * 2).to(dev)
     v = (torch.rand(1, n, generator=g) / n).to(dev)
-    t1 = timed(lambda: hip.softmin_fwd_raw(x, y, h, 0.05 ** 2 * D / 3, 2))
+    eps = 0.05 ** 2 * D / 3
+    t1 = timed(lambda: hip.softmin_fwd_raw(x, y, h, eps, 2))
     t2 = timed(lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, x, y, v, 0.05 * (D / 3) ** 0.5))
     cyc = lambda ms: ms * 1e-3 * 2.4e9 * 1024 / (float(n) * n / 1024)
-    print(f"D={D:2d}: softmin fwd {t1:8.2f} ms ({cyc(t1):5.0f} cyc / 1024 pairs / SIMD)   gaussian product {t2:8.2f} ms ({cyc(t2):5.0f})", flush=True)
+    line = f"D={D:2d}: softmin fwd {t1:8.2f} ms ({cyc(t1):5.0f} cyc / 1024 pairs / SIMD)   gaussian product {t2:8.2f} ms ({cyc(t2):5.0f})"
+    if os.environ.get("GRAD", "0") == "1":      # the gradient kernels (glhip_wsum_t32.h)
+        out = hip.softmin_fwd_raw(x, y, h, eps, 2)
+        g = torch.randn(1, n, device=dev)
+        t3 = timed(lambda: hip.softmin_bwd_x_raw(x, y, h, out, g, eps, 2), reps=3)
+        line += f"   softmin gradient {t3:8.2f} ms"
+    print(line, flush=True)
