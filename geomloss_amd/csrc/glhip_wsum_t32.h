@@ -27,9 +27,9 @@ template <int D>
 struct T32Shape {      // the 6-slot K layout of XdShape (glhip_softmin_xd.h) without its D >= 4 restriction
     static constexpr int NM = (6 * (D + 1) + 15) / 16;
     static constexpr int NBP = 2 * NM;
-    // columns per LDS tile: (16 NBP + 4 (D + 1)) bytes each; 256 keeps four 4-wave workgroups (RT = 2) per CU up to NBP = 6
-    // (512 left two: LDS-bound occupancy of 2 waves per SIMD for D = 5 .. 7)
-    static constexpr int kTile = NBP <= 10 ? 256 : 128;
+    // columns per LDS tile: (16 NBP + 4 (D + 1)) bytes each, sized so that LDS never caps the kernel below its 4 waves per SIMD
+    // (512 columns left the D = 5 .. 7 kernels two 4-wave workgroups per CU: soft-min gradient at D = 5 230 -> 214 ms)
+    static constexpr int kTile = NBP <= 6 ? 256 : 128;
 };
 
 template <int MODE, int D>
