@@ -287,6 +287,19 @@ __global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc
     if (!FILL && lane == 0) counts[i] = n_starts;
 }
 
+// Pairs of points a block-sparse pattern keeps: one wavefront per row cluster adds (rows of the cluster) x (columns of its runs).
+__global__ void __launch_bounds__(256) kept_pairs_kernel(const int32_t* __restrict__ ranges_rows, const int32_t* __restrict__ slices,
+                                                         const int32_t* __restrict__ red, int Cr, unsigned long long* __restrict__ kept) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= Cr) return;
+    const int begin = i == 0 ? 0 : slices[i - 1], end = slices[i];
+    long long cols = 0;
+    for (int k = begin + lane; k < end; k += 64) cols += red[2 * k + 1] - red[2 * k];
+    for (int off = 32; off > 0; off >>= 1) cols += __shfl_xor(cols, off, 64);
+    if (lane == 0 && cols > 0) atomicAdd(kept, (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * i + 1] - ranges_rows[2 * i]));
+}
+
 // inclusive scan of `counts` (n <= a few 1e5) by a single workgroup -> CSR end offsets
 __global__ void __launch_bounds__(1024) slices_kernel(const int32_t* __restrict__ counts, int n, int32_t* __restrict__ slices) {
     __shared__ int scan[1024];
@@ -393,6 +406,19 @@ int glhip_block_ranges(int kind, const float* rows, const float* cols, const flo
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
     hipLaunchKernelGGL((runs_kernel<true>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, nullptr, slices_cols, red_rows, capacity, status);
     return check_launch("glhip_block_ranges");
+}
+
+int glhip_block_ranges_kept_pairs(const int32_t* ranges_rows, const int32_t* slices_rows, const int32_t* red_cols, int Cr,
+                                  long long* kept, void* stream) {
+    if (Cr < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: Cr < 0");
+    if (!kept) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL kept");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipMemsetAsync(kept, 0, sizeof(long long), st);
+    if (Cr == 0) return GLHIP_OK;
+    if (!ranges_rows || !slices_rows || !red_cols) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL pointer");
+    hipLaunchKernelGGL(kept_pairs_kernel, dim3((Cr + 3) / 4), dim3(256), 0, st, ranges_rows, slices_rows, red_cols, Cr,
+                       reinterpret_cast<unsigned long long*>(kept));
+    return check_launch("glhip_block_ranges_kept_pairs");
 }
 
 }  // extern "C"

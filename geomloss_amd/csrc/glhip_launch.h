@@ -385,6 +385,7 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
     sp.split_stride = (long)B * N * kPart;
     sp.xcd_grid_x = 0;
     sp.xcd_blocks = 0;
+    sp.gather = (n_ranges > 0 && N / n_ranges < 128) ? 1 : 0;   // small clusters: gathered tiles, as in launch_softmin_mfma_nw
     const int gx = (N + kRows - 1) / kRows;
     const dim3 merge_grid((N + kBlock - 1) / kBlock, B, 1);
     const XdPacked none{nullptr, 0};

@@ -175,14 +175,14 @@ __device__ __forceinline__ void open_interval(const Ranges& rg, int M, int q_end
 // columns of the tile, and the cursor after it.  The walk over the intervals is wave-uniform (scalar loads and loop control).
 // `pieces`: how many interval pieces a tile may hold — 1 = one tile per piece (long intervals: the walk below would only delay
 // the prefetch; measured 1 % at N = 1e6), kTileX = gather freely (short intervals).  The host decides per launch (SplitInfo::gather).
-template <int K, int THREADS>
+template <int K, int THREADS, int TILE = kTileX>
 __device__ __forceinline__ TileCursor gather_tile(const Ranges& rg, int M, int q_end, int split, int ns, TileCursor c, int tid,
                                                   int (&cols)[K], int& n, int pieces) {
 #pragma unroll
     for (int k = 0; k < K; ++k) cols[k] = -1;
     int off = 0;
-    while (c.q < q_end && off < kTileX && pieces-- > 0) {
-        const int len = min(c.je - c.j0, kTileX - off);
+    while (c.q < q_end && off < TILE && pieces-- > 0) {
+        const int len = min(c.je - c.j0, TILE - off);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int t = tid + k * THREADS - off;

@@ -297,12 +297,10 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
         if (PRE && pre_js < pre_je) stage(pre_js, 0);
         int pre_t = 0;
 
-        for (int q = q_begin + (SPARSE ? split : 0); q < q_end; q += (SPARSE ? ns : 1)) {
-            int js, je;
-            if (PRE) { js = pre_js; je = pre_je; }
-            else column_interval<SPARSE>(rg, M, q, split, ns, js, je);
-            for (int j0 = js; j0 < je; j0 += kTileD) {
-                const int n = min(kTileD, je - j0);
+        // one tile: n real columns (padded to whole groups) starting at column j0 of the interval ending at je — or, block-sparse,
+        // the gathered columns gcols (glhip_softmin_x32.h: gather_tile)
+        constexpr int kCols = (kTileD + kThreads - 1) / kThreads;
+        auto tile_body = [&](int j0, int je, int n, const int (&gcols)[kCols]) {
                 const int npad = (n + 31) & ~31;
                 const uint4* tile = tileBuf;
                 const float* tileV = tileVBuf;
@@ -315,12 +313,22 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                     ++pre_t;
                 } else {
                     __syncthreads();
-                    for (int t = tid; t < npad; t += kThreads)
-                        pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32,
-                                                   &tileVBuf[MODE == XD_GAUSS ? t : 0]);
+                    if (SPARSE) {      // gathered tile: slot t holds column gcols[k] (t = tid + k kThreads)
+#pragma unroll
+                        for (int k = 0; k < kCols; ++k) {
+                            const int t = tid + k * kThreads;
+                            if (t < npad)
+                                pack_column_xd<MODE, D, T>(prm, (long)b * M + max(gcols[k], 0), t < n, centre,
+                                                           &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32, &tileVBuf[MODE == XD_GAUSS ? t : 0]);
+                        }
+                    } else {
+                        for (int t = tid; t < npad; t += kThreads)
+                            pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32,
+                                                       &tileVBuf[MODE == XD_GAUSS ? t : 0]);
+                    }
                     __syncthreads();
                 }
-                if (!wave_active) continue;
+                if (!wave_active) return;
 
                 const int nG = npad / 32;
                 if (MODE == XD_GAUSS) {
@@ -330,7 +338,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         for (int rt = 0; rt < RT; ++rt)
                             ssum[rt] += xd_weighted_sum(xd_block<NM, NBP>(g, rec0, X[rt], zero16), &tileV[G * 32 + half * 4]);
                     }
-                    continue;
+                    return;
                 }
 
                 int G0 = 0;
@@ -384,7 +392,27 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
                 }
+        };
+        if (SPARSE) {
+            // Block-sparse launches walk the concatenation of their column intervals: with small clusters (SplitInfo::gather) a tile
+            // gathers as many intervals as fit, otherwise one piece of one interval, as before
+            TileCursor cur;
+            cur.q = q_begin + split;
+            cur.j0 = cur.je = 0;
+            open_interval<true, true>(rg, M, q_end, split, ns, cur);
+            const int pieces = sp.gather ? kTileD : 1;
+            while (cur.q < q_end) {
+                int gcols[kCols], n = 0;
+                const TileCursor nxt = gather_tile<kCols, kThreads, kTileD>(rg, M, q_end, split, ns, cur, tid, gcols, n, pieces);
+                tile_body(0, 0, n, gcols);
+                cur = nxt;
             }
+        } else {
+            int js, je;
+            if (PRE) { js = pre_js; je = pre_je; }
+            else column_interval<false>(rg, M, 0, split, ns, js, je);
+            const int none[kCols] = {};
+            for (int j0 = js; j0 < je; j0 += kTileD) tile_body(j0, je, min(kTileD, je - j0), none);
         }
 
         if (wave_active) {

@@ -59,6 +59,7 @@ SIGNATURES = {
     "glhip_block_ranges": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 6
                            + [ctypes.c_longlong, _vp, _vp]),
     "glhip_block_ranges_count": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 5 + [_vp]),
+    "glhip_block_ranges_kept_pairs": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _vp]),
 }
 _c_double = ctypes.c_double
 SIGNATURES.update({
@@ -442,6 +443,17 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
     if counted and int(status.item()) != 0:
         raise RuntimeError("geomloss_amd: glhip_block_ranges wrote more intervals than its counting pass announced.")
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
+
+
+def kept_pairs(ranges):
+    """Pairs of points a :class:`BlockRanges` keeps (``glhip_block_ranges_kept_pairs``): one small read-back."""
+    lib = load_library()
+    Cr = int(ranges.ranges_i.shape[0])
+    with torch.cuda.device(ranges.ranges_i.device):
+        kept = torch.empty(1, dtype=torch.int64, device=ranges.ranges_i.device)
+        _check(lib.glhip_block_ranges_kept_pairs(ranges.ranges_i.data_ptr(), ranges.slices_i.data_ptr(), ranges.redranges_j.data_ptr(), Cr,
+                                                 kept.data_ptr(), _stream(ranges.ranges_i)), lib)
+    return int(kept.item())
 
 
 # ----------------------------------------------------------------------------------------------

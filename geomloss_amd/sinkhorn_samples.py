@@ -13,6 +13,7 @@ The Sinkhorn loop itself lives in :mod:`geomloss_amd.sinkhorn_divergence`; the k
 through :mod:`geomloss_amd.hip`.
 """
 
+import math
 import os
 from functools import partial
 
@@ -324,8 +325,54 @@ def clusterize(a, x, scale=None, labels=None):
     return [a_c, a[perm]], [x_c, x[perm]], [ranges_x], perm
 
 
-def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False):
-    """Keeps the fine blocks whose coarse dual slack allows mass: f_i + g_j > C_ij - truncate * eps (``:493-530``)."""
+# A truncated fine level is an optimisation, and not always one.  The reference's voxel rule makes ~2000 clusters whatever N is, so
+# below ~3e4 points a cluster holds a handful of them and a block-sparse launch fills a fraction of its 32-row tiles (N = 1e4, D = 3:
+# 99 us per soft-min against 10 us for the dense kernel on the same points); and labels that leave a coordinate out (the reference's
+# 4-D recipe clusters the 3 spatial coordinates of position + feature points) give clusters as wide as the cloud, of which the rule
+# keeps 86 %.  Once the pattern is built its kept pairs are counted (one 8-byte read-back) and costed against the dense launch:
+#     block-sparse ~ kept / (kDenseRate * fill),   fill = filled share of the 32-row tiles of a mean cluster,   dense ~ N M
+# and the cheaper one runs — the fine level of `truncate=None` (``:504-505``).  Only where that cannot move a result: a dropped
+# pair has an exponent below -truncate at the temperature of the jump and, the loop annealing on, below -truncate * eps_jump / eps_last
+# in the iterations that decide the answer; the switch needs that bound to be 16 (1e-7 of a row's mass: float32 resolution).  The
+# defaults qualify for p = 2 (5 x (0.108 / 0.05)^2 = 23 on the unit cube), not for p = 1 (5 x 2.2 = 11), which keeps its pattern.
+# GEOMLOSS_HIP_DENSE_SWITCH=0 keeps the pattern everywhere (A/B, tests).
+_DENSE_SWITCH = os.environ.get("GEOMLOSS_HIP_DENSE_SWITCH", "1")
+_DENSE_SWITCH_MIN_EXPONENT = 16.0
+_DENSE_SWITCH_RATE = 0.45         # pairs per second of a block-sparse launch with full tiles, as a share of the dense kernel's (fitted: tools/probe_dense_switch.py)
+
+
+def set_dense_switch(mode):
+    """"1": cost model, "0": always block-sparse, "always": always dense (tests)."""
+    global _DENSE_SWITCH
+    _DENSE_SWITCH = str(mode)
+
+
+def dense_is_cheaper(kept, N, M, Cr, Cc):
+    """The cost model above for both orientations of a pattern (N x M points, Cr x Cc clusters, `kept` pairs of points)."""
+    if N <= 0 or M <= 0 or Cr <= 0 or Cc <= 0:
+        return False
+
+    def fill(points, clusters):
+        mean = points / clusters
+        return mean / (32.0 * math.ceil(mean / 32.0))
+
+    sparse = 0.5 * kept / _DENSE_SWITCH_RATE * (1.0 / fill(N, Cr) + 1.0 / fill(M, Cc))
+    return sparse > float(N) * float(M)
+
+
+def _goes_dense(truncate, eps, eps_last, N, M, Cr, Cc, kept_pairs):
+    """`kept_pairs`: callable, the read-back is only paid where the switch may apply."""
+    if _DENSE_SWITCH == "always":
+        return True
+    if _DENSE_SWITCH == "0" or eps_last is None or truncate * eps / eps_last < _DENSE_SWITCH_MIN_EXPONENT:
+        return False
+    return dense_is_cheaper(kept_pairs(), N, M, Cr, Cc)
+
+
+def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False, eps_last=None):
+    """Keeps the fine blocks whose coarse dual slack allows mass: f_i + g_j > C_ij - truncate * eps (``:493-530``).
+    ``eps_last`` (not in the reference): the last temperature of the loop, which lets the fine level stay dense where that is cheaper
+    and changes nothing (see above); None: always the pattern."""
     if truncate is None:
         return C_xy_, C_yx_
     x, yd, ranges_x, ranges_y, _ = C_xy
@@ -335,19 +382,30 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
     if native_p is not None and native_clustering_applies(x):
         ranges_xy_ = block_ranges_device("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps, p=native_p)
+        dense = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], lambda: hip.kept_pairs(ranges_xy_))
         if verbose:     # the printed statistic only: the ranges above are the ones a silent run builds (same kernels either way)
             with torch.no_grad():
                 C = cost(x, y)
                 ks, Cs = (f_ba.view(-1, 1) + g_ab.view(1, -1) > C - truncate * eps).sum(), C.shape[0] * C.shape[1]
             print("Keep {}/{} = {:2.1f}% of the coarse cost matrix.".format(ks, Cs, 100 * float(ks) / Cs))
+        if dense:      # dense fine level: the cost objects of a single-scale loop
+            return (x_, yd_, None, None, None), (y_, xd_, None, None, None)
         return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
     with torch.no_grad():
         C = cost(x, y)
         keep = f_ba.view(-1, 1) + g_ab.view(1, -1) > C - truncate * eps
-        ranges_xy_ = from_matrix(ranges_x, ranges_y, keep)
         if verbose:
             ks, Cs = keep.sum(), C.shape[0] * C.shape[1]
             print("Keep {}/{} = {:2.1f}% of the coarse cost matrix.".format(ks, Cs, 100 * float(ks) / Cs))
+
+        def kept_pairs():
+            rows = (ranges_x[:, 1] - ranges_x[:, 0]).double()
+            cols = (ranges_y[:, 1] - ranges_y[:, 0]).double()
+            return float(rows @ (keep.double() @ cols))
+
+        if x_.is_cuda and _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], kept_pairs):
+            return (x_, yd_, None, None, None), (y_, xd_, None, None, None)
+        ranges_xy_ = from_matrix(ranges_x, ranges_y, keep)
     return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
 
 
@@ -414,7 +472,7 @@ def sinkhorn_multiscale(
 
     f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
         softmin, a_logs, b_logs, C_xxs, C_yys, C_xys, C_yxs, eps_list, rho,
-        jumps=jumps, cost=cost_routine, kernel_truncation=partial(kernel_truncation, verbose=verbose),
+        jumps=jumps, cost=cost_routine, kernel_truncation=partial(kernel_truncation, verbose=verbose, eps_last=eps_list[-1]),
         truncate=truncate, extrapolate=extrapolate, debias=debias,
     )
 

@@ -325,6 +325,13 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
                              int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
                              int32_t* slices_rows, int32_t* slices_cols, int32_t* totals, void* stream);
 
+/* Pairs of POINTS a pattern keeps: kept (1) int64 out = sum over the row clusters of (rows of the cluster) x (columns of its
+ * intervals), from the (ranges_rows, slices_rows, red_cols) of glhip_block_ranges.  The reference prints this figure at the level of
+ * clusters when verbose (sinkhorn_samples.py:522-528); the host side uses it to cost a block-sparse launch against a dense one
+ * (geomloss_amd/sinkhorn_samples.py: kernel_truncation). */
+int glhip_block_ranges_kept_pairs(const int32_t* ranges_rows, const int32_t* slices_rows, const int32_t* red_cols, int Cr,
+                                  long long* kept, void* stream);
+
 /* ---- the four reductions in DOUBLE precision (round 4) ---------------------------------------------------------------------
  * The reference's matrix-free backends keep the dtype of their inputs: float64 clouds are reduced in float64 by KeOps
  * (softmin_online_lazytensor, sinkhorn_samples.py:229-290, `.logsumexp` on LazyTensors of the input dtype; lse_genred :322-334

@@ -431,3 +431,35 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_dense_switch_cost_model_and_exponent_gate():
+    """sinkhorn_samples.dense_is_cheaper / _goes_dense: the fine level of a two-scale loss stays dense when the pattern keeps most of
+    the matrix or its clusters fill a fraction of the 32-row tiles — and only where the dropped pairs cannot matter."""
+    import geomloss_amd.sinkhorn_samples as ss
+    # measured on an MI355X (tools/probe_dense_switch.py): D = 3 keeps 21 % at every N; dense wins up to 3e4 points, the pattern from 1e5
+    assert ss.dense_is_cheaper(0.21 * 1e4 ** 2, 10_000, 10_000, 2000, 2000)
+    assert ss.dense_is_cheaper(0.21 * 3e4 ** 2, 30_000, 30_000, 2140, 2140)
+    assert not ss.dense_is_cheaper(0.21 * 1e5 ** 2, 100_000, 100_000, 2170, 2170)
+    assert not ss.dense_is_cheaper(0.21 * 1e6 ** 2, 1_000_000, 1_000_000, 2197, 2197)
+    assert ss.dense_is_cheaper(0.88 * 2e5 ** 2, 200_000, 200_000, 2197, 2197)           # 4-D clouds clustered on 3 coordinates
+    assert not ss.dense_is_cheaper(0, 0, 10, 0, 3)
+
+    def never():
+        raise AssertionError("the pairs are only counted where the switch may apply")
+
+    eps_jump, eps_last = 0.108 ** 2, 0.05 ** 2
+    old = ss._DENSE_SWITCH
+    try:
+        ss.set_dense_switch("1")
+        assert not ss._goes_dense(5, 0.108, 0.05, 10_000, 10_000, 2000, 2000, never)           # p = 1: 5 x 2.2 < 16
+        assert not ss._goes_dense(2, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never)     # truncate = 2
+        assert not ss._goes_dense(5, eps_jump, None, 10_000, 10_000, 2000, 2000, never)         # a caller that does not say
+        assert ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, lambda: 0.21e8)
+        assert not ss._goes_dense(5, eps_jump, eps_last, 100_000, 100_000, 2170, 2170, lambda: 0.21e10)
+        ss.set_dense_switch("0")
+        assert not ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never)
+        ss.set_dense_switch("always")
+        assert ss._goes_dense(2, eps_jump, None, 10, 10, 2, 2, never)
+    finally:
+        ss.set_dense_switch(old)

@@ -97,8 +97,17 @@ def _two_clouds(seed, N, M, D=3, kind="shifted"):
     return x, y
 
 
+@pytest.fixture(params=["1", "0"], ids=["dense-where-cheaper", "always-truncated"])
+def fine_level(request, monkeypatch):
+    """The truncated fine level as the cost model picks it (at these sizes: dense launches, sinkhorn_samples.dense_is_cheaper) and
+    always block-sparse: both must match the two-scale oracle, which always truncates."""
+    import geomloss_amd.sinkhorn_samples as ss
+    monkeypatch.setattr(ss, "_DENSE_SWITCH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("kind,scaling", [("shifted", 0.5), ("same", 0.7), ("shifted", 0.9)])
-def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling):
+def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling, fine_level):
     """cfg-3 parity: same clustering, same truncation rule, same loop as the reference's
     two-scale algorithm, emulated in fp64 with dense masked matrices."""
     N, M = 3500, 3000
@@ -267,7 +276,7 @@ def test_full_size_block_sparse_equals_dense_when_everything_is_kept(cuda):
     dict(p=2, blur=0.05, scaling=0.7, truncate=2),          # tighter truncation
     dict(p=2, blur=0.05, scaling=0.7, cluster_scale=0.2),   # user voxel size (few, large clusters)
 ])
-def test_multiscale_variants_match_two_scale_oracle(cuda, kw):
+def test_multiscale_variants_match_two_scale_oracle(cuda, kw, fine_level):
     N, M = 2600, 2400
     x, y = _two_clouds(21, N, M, kind="shifted")
     rng = np.random.default_rng(22)
@@ -433,3 +442,41 @@ def test_kernel_product_under_no_grad_skips_the_gradient_kernel(cuda):
             assert torch.equal(hip.kernel_conv(name, xg, y, v, 0.1), plain)
         out = hip.kernel_conv(name, xg, y, v, 0.1)
         assert out.requires_grad and torch.allclose(out, plain, rtol=1e-4, atol=1e-6)
+
+
+def test_dense_fine_level_where_cheaper(cuda, monkeypatch):
+    """kernel_truncation counts the pairs of points its pattern keeps (glhip_block_ranges_kept_pairs) and leaves the fine level dense
+    where a block-sparse launch would cost more (clusters of a few points, or a rule that keeps most of the matrix): the reference's
+    own `truncate=None` fine level.  The count against NumPy; the decision on a 4-D cloud (kept: ~80 %) — dense launches, the same
+    loss as the truncated run to float32 rounding — and not taken for p = 1, whose dropped pairs are not negligible."""
+    import geomloss_amd.sinkhorn_samples as ss
+    from geomloss_amd import hip
+    from geomloss_amd.cluster import from_matrix
+    rng = np.random.default_rng(5)
+    cut_i, cut_j = np.sort(rng.choice(np.arange(1, 5000), 36, replace=False)), np.sort(rng.choice(np.arange(1, 4000), 40, replace=False))
+    ri = np.stack([np.r_[0, cut_i], np.r_[cut_i, 5000]], 1).astype(np.int32)
+    rj = np.stack([np.r_[0, cut_j], np.r_[cut_j, 4000]], 1).astype(np.int32)
+    keep = rng.random((37, 41)) < 0.3
+    keep[3, :] = False
+    rg = from_matrix(torch.from_numpy(ri).to(cuda), torch.from_numpy(rj).to(cuda), torch.from_numpy(keep).to(cuda))
+    want = int((ri[:, 1] - ri[:, 0]).astype(np.int64) @ keep.astype(np.int64) @ (rj[:, 1] - rj[:, 0]).astype(np.int64))
+    assert hip.kept_pairs(rg) == want and hip.kept_pairs(rg.t()) == want
+
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.rand(6000, 4, generator=g).to(cuda), torch.rand(5000, 4, generator=g).to(cuda)
+    launches = []
+    real = hip.softmin
+    monkeypatch.setattr(hip, "softmin", lambda *a, **k: (launches.append(k.get("ranges") is not None), real(*a, **k))[1])
+    real_step = hip.sinkhorn_step
+    monkeypatch.setattr(hip, "sinkhorn_step", lambda *a, **k: (launches.append(k.get("ranges") is not None), real_step(*a, **k))[1])
+    out = {}
+    for mode in ("0", "1", "always"):
+        monkeypatch.setattr(ss, "_DENSE_SWITCH", mode)
+        del launches[:]
+        out[mode] = (SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")(x, y).item(), any(launches))
+    assert out["0"][1] and not out["1"][1] and not out["always"][1]          # block-sparse launches only when forced
+    assert out["1"][0] == out["always"][0] and abs(out["1"][0] - out["0"][0]) < 1e-5 * abs(out["0"][0])
+    monkeypatch.setattr(ss, "_DENSE_SWITCH", "1")
+    del launches[:]
+    SamplesLoss("sinkhorn", p=1, blur=0.05, backend="multiscale")(x[:, :3].contiguous(), y[:, :3].contiguous())
+    assert any(launches)                                                      # p = 1 keeps its pattern

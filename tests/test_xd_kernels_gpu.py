@@ -171,12 +171,13 @@ def _random_ranges(rng, N, M, ci, cj, density, dev):
     return rg, tup, ri
 
 
-@pytest.mark.parametrize("D", [4, 9])
-def test_block_sparse_softmin_and_gaussian(cuda, D):
+@pytest.mark.parametrize("D,ci,cj", [(4, 9, 11), (9, 9, 11), (4, 60, 70), (9, 60, 70), (16, 60, 70)])
+def test_block_sparse_softmin_and_gaussian(cuda, D, ci, cj):
+    # 60 x 70 clusters: row clusters of ~40 points, whose tiles gather several column intervals (SplitInfo::gather)
     rng = np.random.default_rng(17)
     N, M = 2300, 2600
     x, y, h = _clouds(23, N, M, D)
-    rg, tup, ri = _random_ranges(rng, N, M, 9, 11, 0.4, cuda)
+    rg, tup, ri = _random_ranges(rng, N, M, ci, cj, 0.4, cuda)
     eps = 0.02
     ref = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
     empty = slice(ri[0, 0], ri[0, 1])

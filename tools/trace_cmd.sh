@@ -11,8 +11,8 @@ for db in glob.glob("$OUT/*.db"):
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     tot = sum(r[2] for r in rows)
-    print(f"total kernel time {tot/1e3:.1f} us over {sum(r[1] for r in rows)} launches")
-    for r in rows[:24]:
-        print(f"{r[4]:6.2f}%  calls {r[1]:5d}  avg {r[3]/1e3:10.2f} us  {r[0][:150]}")
+    print(f"total kernel time {tot/1e3:.2f} ms over {sum(r[1] for r in rows)} launches")      # the view's durations are in microseconds
+    for r in rows[:int("${TOP:-12}")]:
+        print(f"{r[4]:6.2f}%  calls {r[1]:5d}  avg {r[3]:10.2f} us  {r[0][:150]}")
 PY
 find $OUT -size +4M -delete
