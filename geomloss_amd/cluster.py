@@ -140,6 +140,15 @@ def clusterize_device(a, x, scale, pre_div=1.0):
     return w_c, ws, cents.to(x.dtype), xs, ranges, perm
 
 
+def kept_pairs_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+    """Pairs of points the keep rule of :func:`block_ranges_device` retains (same arguments), counted without building the pattern."""
+    from . import hip
+    code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
+    f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
+    return hip.kept_pairs_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),
+                              ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p)
+
+
 def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
     """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``; interval buffers sized from its
     counting pass once the worst case would be large).  ``kind``: "dual_slack"

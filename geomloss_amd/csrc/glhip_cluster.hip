@@ -287,15 +287,16 @@ __global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc
     if (!FILL && lane == 0) counts[i] = n_starts;
 }
 
-// Pairs of points a block-sparse pattern keeps: one wavefront per row cluster adds (rows of the cluster) x (columns of its runs).
-__global__ void __launch_bounds__(256) kept_pairs_kernel(const int32_t* __restrict__ ranges_rows, const int32_t* __restrict__ slices,
-                                                         const int32_t* __restrict__ red, int Cr, unsigned long long* __restrict__ kept) {
+// Pairs of POINTS a keep rule retains, without building its intervals: one wavefront per row cluster adds
+// (rows of the cluster) x (columns of the kept column clusters).
+__global__ void __launch_bounds__(256) kept_pairs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_rows,
+                                                         const int32_t* __restrict__ ranges_cols, unsigned long long* __restrict__ kept) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Cr) return;
-    const int begin = i == 0 ? 0 : slices[i - 1], end = slices[i];
     long long cols = 0;
-    for (int k = begin + lane; k < end; k += 64) cols += red[2 * k + 1] - red[2 * k];
+    for (int c = lane; c < Cc; c += 64)
+        if (keep_pair(rule, i, c)) cols += ranges_cols[2 * c + 1] - ranges_cols[2 * c];
     for (int off = 32; off > 0; off >>= 1) cols += __shfl_xor(cols, off, 64);
     if (lane == 0 && cols > 0) atomicAdd(kept, (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * i + 1] - ranges_rows[2 * i]));
 }
@@ -408,15 +409,19 @@ int glhip_block_ranges(int kind, const float* rows, const float* cols, const flo
     return check_launch("glhip_block_ranges");
 }
 
-int glhip_block_ranges_kept_pairs(const int32_t* ranges_rows, const int32_t* slices_rows, const int32_t* red_cols, int Cr,
-                                  long long* kept, void* stream) {
-    if (Cr < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: Cr < 0");
+int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D,
+                                  int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, long long* kept, void* stream) {
+    if (kind != GLHIP_KEEP_DUAL_SLACK && kind != GLHIP_KEEP_WITHIN) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: bad kind %d", kind);
+    if (Cr < 0 || Cc < 0 || D < 1) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: bad sizes");
+    if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_block_ranges_kept_pairs: p must be 1 or 2");
     if (!kept) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL kept");
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(kept, 0, sizeof(long long), st);
-    if (Cr == 0) return GLHIP_OK;
-    if (!ranges_rows || !slices_rows || !red_cols) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL pointer");
-    hipLaunchKernelGGL(kept_pairs_kernel, dim3((Cr + 3) / 4), dim3(256), 0, st, ranges_rows, slices_rows, red_cols, Cr,
+    if (Cr == 0 || Cc == 0) return GLHIP_OK;
+    if (!rows || !cols || !ranges_rows || !ranges_cols || (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
+        return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL pointer");
+    const KeepRule rule{kind, rows, cols, f, g, D, p, thr};
+    hipLaunchKernelGGL(kept_pairs_kernel, dim3((Cr + 3) / 4), dim3(256), 0, st, rule, Cr, Cc, ranges_rows, ranges_cols,
                        reinterpret_cast<unsigned long long*>(kept));
     return check_launch("glhip_block_ranges_kept_pairs");
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     "glhip_block_ranges": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 6
                            + [ctypes.c_longlong, _vp, _vp]),
     "glhip_block_ranges_count": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 5 + [_vp]),
-    "glhip_block_ranges_kept_pairs": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _vp]),
+    "glhip_block_ranges_kept_pairs": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float] + [_vp] * 4),
 }
 _c_double = ctypes.c_double
 SIGNATURES.update({
@@ -445,14 +445,17 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
 
-def kept_pairs(ranges):
-    """Pairs of points a :class:`BlockRanges` keeps (``glhip_block_ranges_kept_pairs``): one small read-back."""
+def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+    """Pairs of points the keep rule of :func:`block_ranges_raw` retains (``glhip_block_ranges_kept_pairs``; same arguments): one
+    launch and one 8-byte read-back, no intervals built."""
     lib = load_library()
-    Cr = int(ranges.ranges_i.shape[0])
-    with torch.cuda.device(ranges.ranges_i.device):
-        kept = torch.empty(1, dtype=torch.int64, device=ranges.ranges_i.device)
-        _check(lib.glhip_block_ranges_kept_pairs(ranges.ranges_i.data_ptr(), ranges.slices_i.data_ptr(), ranges.redranges_j.data_ptr(), Cr,
-                                                 kept.data_ptr(), _stream(ranges.ranges_i)), lib)
+    Cr, D = rows.shape
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(rows.device):
+        kept = torch.empty(1, dtype=torch.int64, device=rows.device)
+        _check(lib.glhip_block_ranges_kept_pairs(int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, cols.shape[0], D, int(p),
+                                                 float(thr), ranges_rows.data_ptr(), ranges_cols.data_ptr(), kept.data_ptr(),
+                                                 _stream(rows)), lib)
     return int(kept.item())
 
 

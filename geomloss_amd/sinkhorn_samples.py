@@ -22,7 +22,7 @@ import torch
 
 from . import hip
 from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, from_matrix, grid_cluster,
-                      native_clustering_applies, swap_axes)
+                      kept_pairs_device, native_clustering_applies, swap_axes)
 from .sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
@@ -329,7 +329,8 @@ def clusterize(a, x, scale=None, labels=None):
 # below ~3e4 points a cluster holds a handful of them and a block-sparse launch fills a fraction of its 32-row tiles (N = 1e4, D = 3:
 # 99 us per soft-min against 10 us for the dense kernel on the same points); and labels that leave a coordinate out (the reference's
 # 4-D recipe clusters the 3 spatial coordinates of position + feature points) give clusters as wide as the cloud, of which the rule
-# keeps 86 %.  Once the pattern is built its kept pairs are counted (one 8-byte read-back) and costed against the dense launch:
+# keeps 86 %.  Before the pattern is built the pairs its rule keeps are counted (one launch, one 8-byte read-back) and costed against
+# the dense launch:
 #     block-sparse ~ kept / (kDenseRate * fill),   fill = filled share of the 32-row tiles of a mean cluster,   dense ~ N M
 # and the cheaper one runs — the fine level of `truncate=None` (``:504-505``).  Only where that cannot move a result: a dropped
 # pair has an exponent below -truncate at the temperature of the jump and, the loop annealing on, below -truncate * eps_jump / eps_last
@@ -381,8 +382,9 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     y_, xd_, _, _, _ = C_yx_
     native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
     if native_p is not None and native_clustering_applies(x):
-        ranges_xy_ = block_ranges_device("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps, p=native_p)
-        dense = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], lambda: hip.kept_pairs(ranges_xy_))
+        rule = ("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps)
+        dense = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], lambda: kept_pairs_device(*rule, p=native_p))
+        ranges_xy_ = None if dense else block_ranges_device(*rule, p=native_p)
         if verbose:     # the printed statistic only: the ranges above are the ones a silent run builds (same kernels either way)
             with torch.no_grad():
                 C = cost(x, y)

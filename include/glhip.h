@@ -325,12 +325,13 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
                              int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols,
                              int32_t* slices_rows, int32_t* slices_cols, int32_t* totals, void* stream);
 
-/* Pairs of POINTS a pattern keeps: kept (1) int64 out = sum over the row clusters of (rows of the cluster) x (columns of its
- * intervals), from the (ranges_rows, slices_rows, red_cols) of glhip_block_ranges.  The reference prints this figure at the level of
- * clusters when verbose (sinkhorn_samples.py:522-528); the host side uses it to cost a block-sparse launch against a dense one
- * (geomloss_amd/sinkhorn_samples.py: kernel_truncation). */
-int glhip_block_ranges_kept_pairs(const int32_t* ranges_rows, const int32_t* slices_rows, const int32_t* red_cols, int Cr,
-                                  long long* kept, void* stream);
+/* Pairs of POINTS the keep rule of glhip_block_ranges retains (same arguments), without building the intervals:
+ * kept (1) int64 out = sum over the kept cluster pairs (i, j) of |rows_i| x |cols_j|.  The reference prints this figure at the level
+ * of clusters when verbose (sinkhorn_samples.py:516-522); the host side costs a block-sparse fine level against a dense one with it
+ * BEFORE building the pattern (geomloss_amd/sinkhorn_samples.py: kernel_truncation; `truncate=None` at :504-505 is the dense one). */
+int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
+                                  int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, long long* kept,
+                                  void* stream);
 
 /* ---- the four reductions in DOUBLE precision (round 4) ---------------------------------------------------------------------
  * The reference's matrix-free backends keep the dtype of their inputs: float64 clouds are reduced in float64 by KeOps

@@ -445,22 +445,26 @@ def test_kernel_product_under_no_grad_skips_the_gradient_kernel(cuda):
 
 
 def test_dense_fine_level_where_cheaper(cuda, monkeypatch):
-    """kernel_truncation counts the pairs of points its pattern keeps (glhip_block_ranges_kept_pairs) and leaves the fine level dense
+    """kernel_truncation counts the pairs of points its rule keeps (glhip_block_ranges_kept_pairs) and leaves the fine level dense
     where a block-sparse launch would cost more (clusters of a few points, or a rule that keeps most of the matrix): the reference's
     own `truncate=None` fine level.  The count against NumPy; the decision on a 4-D cloud (kept: ~80 %) — dense launches, the same
     loss as the truncated run to float32 rounding — and not taken for p = 1, whose dropped pairs are not negligible."""
     import geomloss_amd.sinkhorn_samples as ss
     from geomloss_amd import hip
-    from geomloss_amd.cluster import from_matrix
+    from geomloss_amd.cluster import block_ranges_device, kept_pairs_device
     rng = np.random.default_rng(5)
     cut_i, cut_j = np.sort(rng.choice(np.arange(1, 5000), 36, replace=False)), np.sort(rng.choice(np.arange(1, 4000), 40, replace=False))
     ri = np.stack([np.r_[0, cut_i], np.r_[cut_i, 5000]], 1).astype(np.int32)
     rj = np.stack([np.r_[0, cut_j], np.r_[cut_j, 4000]], 1).astype(np.int32)
-    keep = rng.random((37, 41)) < 0.3
-    keep[3, :] = False
-    rg = from_matrix(torch.from_numpy(ri).to(cuda), torch.from_numpy(rj).to(cuda), torch.from_numpy(keep).to(cuda))
-    want = int((ri[:, 1] - ri[:, 0]).astype(np.int64) @ keep.astype(np.int64) @ (rj[:, 1] - rj[:, 0]).astype(np.int64))
-    assert hip.kept_pairs(rg) == want and hip.kept_pairs(rg.t()) == want
+    for kind, p in (("dual_slack", 2), ("dual_slack", 1), ("within", 2)):
+        ci, cj = torch.from_numpy(rng.random((37, 3), dtype=np.float32)).to(cuda), torch.from_numpy(rng.random((41, 3), dtype=np.float32)).to(cuda)
+        f, g_ = torch.from_numpy(rng.random(37, dtype=np.float32) * 0.1).to(cuda), torch.from_numpy(rng.random(41, dtype=np.float32) * 0.1).to(cuda)
+        rule = (kind, ci, cj, f, g_, torch.from_numpy(ri).to(cuda), torch.from_numpy(rj).to(cuda), 0.15)
+        rg = block_ranges_device(*rule, p=p)       # the same rule as intervals: the pairs they cover, counted in NumPy
+        sl, red = rg.slices_i.cpu().numpy(), rg.redranges_j.cpu().numpy().astype(np.int64)
+        want = sum(int(ri[i, 1] - ri[i, 0]) * int((red[(sl[i - 1] if i else 0):sl[i], 1] - red[(sl[i - 1] if i else 0):sl[i], 0]).sum())
+                   for i in range(37))
+        assert 0 < want < 5000 * 4000 and kept_pairs_device(*rule, p=p) == want
 
     g = torch.Generator().manual_seed(8)
     x, y = torch.rand(6000, 4, generator=g).to(cuda), torch.rand(5000, 4, generator=g).to(cuda)
