@@ -269,6 +269,9 @@ def sinkhorn_wallclock(dev):
 
     run("multiscale_1e6_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 1_000_000, False)
     run("multiscale_1e6_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 1_000_000, True)
+    # the sizes from which the reference's backend="auto" picks the two-scale solver (N M > 1e8): clusters of a few points
+    run("multiscale_1e4_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 10_000, False, reps=4)
+    run("multiscale_1e5_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale"), 100_000, False, reps=3)
     run("online_1e5_fwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, False)
     run("online_1e5_fwd_bwd", SamplesLoss("sinkhorn", p=2, blur=0.05, backend="online"), 100_000, True)
     run("gaussian_online_1e6_fwd", SamplesLoss("gaussian", blur=0.05, backend="online"), 1_000_000, False, reps=1)
