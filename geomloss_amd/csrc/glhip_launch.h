@@ -151,6 +151,16 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         else hipLaunchKernelGGL((pack_columns_kernel<D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
     };
 
+    if constexpr (NW == 2) {    // block-sparse launches on row blocks of up to 64 points only (launch_softmin_mfma)
+        if (plan_pre(sp.n_splits)) {
+            pack();
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
+        } else {
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, false>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, PackedCols{nullptr, 0});
+        }
+        if (sp.n_splits > 1)
+            hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
+    } else {
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -191,6 +201,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
     }
+    }
 }
 
 template <int D, typename T, int KIND>
@@ -201,8 +212,13 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     // block-sparse with row blocks of a few hundred points (multiscale at 1e6: 0.27 vs 0.30 s); 4 wavefronts when
     // every workgroup packs its own tiles or the row blocks are small, where more, smaller workgroups win.
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
+    static const int small_rows = getenv("GLHIP_FWD_NW2_ROWS") ? atoi(getenv("GLHIP_FWD_NW2_ROWS")) : 64;
     if (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
+    else if (KIND == FWD_X32 && n_ranges > 0 && !forced_nw && N / n_ranges <= small_rows)
+        // row blocks of up to 64 points (the reference's ~2000 clusters on clouds of up to ~1.4e5 points): 2 wavefronts x 256-column
+        // tiles — in a 4-wavefront workgroup half the wavefronts would own no row and only stage and wait
+        launch_softmin_mfma_nw<D, T, FWD_X32, 2>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (forced_nw ? forced_nw == 8
                        : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
         launch_softmin_mfma_nw<D, T, KIND == FWD_F32 ? FWD_XDL16 : KIND, 8>(prm, rg, n_ranges, B, N, M, sc, st);

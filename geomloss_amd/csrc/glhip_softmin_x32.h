@@ -199,7 +199,11 @@ __device__ __forceinline__ TileCursor gather_tile(const Ranges& rg, int M, int q
     return c;
 }
 
-// The work of one workgroup: row block bx of batch item b, column split `split`.  tileX: kTileX * 4 records of LDS,
+// Columns per LDS tile: 512 (32 KB) for workgroups of 4 / 8 wavefronts; 256 for the 2-wavefront workgroups that serve row blocks of
+// up to 64 points (block-sparse launches on small clusters: twice the workgroups per CU for the same LDS, no idle wavefronts)
+constexpr int fwd_tile(int NW) { return NW == 2 ? 256 : kTileX; }
+
+// The work of one workgroup: row block bx of batch item b, column split `split`.  tileX: kTile * 4 records of LDS,
 // [column group of 32][K block][column], one 16-byte record per (column, K block).
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
 __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm, const Ranges& rg, int N, int M,
@@ -208,8 +212,9 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
-    constexpr int kPer = (kTileX * 4) / kThreads;   // PRE: records one thread moves per tile
-    static_assert((kTileX * 4) % kThreads == 0, "tile / workgroup shape");
+    constexpr int kTile = fwd_tile(NW);
+    constexpr int kPer = (kTile * 4) / kThreads;   // PRE: records one thread moves per tile
+    static_assert((kTile * 4) % kThreads == 0, "tile / workgroup shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -262,7 +267,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         cur.q = q_begin + (SPARSE ? split : 0);
         cur.j0 = cur.je = 0;
         open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, cur);
-        const int pieces = sp.gather ? kTileX : 1;
+        const int pieces = sp.gather ? kTile : 1;
         constexpr bool GATHER = SPARSE && PRE;   // pre-packed: the gathered tile is fetched into registers one tile ahead
         constexpr bool GATHER_NOW = SPARSE && !PRE;   // packed on the fly: gathered when it is staged
         constexpr int kCols = kPer / 4;          // columns a thread moves per tile
@@ -278,24 +283,24 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         };
         if (GATHER) {
             if (cur.q < q_end) {
-                gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
+                gnext = gather_tile<kCols, kThreads, kTile>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
                 fetch_gathered();
             }
         } else if (PRE && cur.q < q_end) {
-            fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(cur.j0), min(kTileX, cur.je - cur.j0), tid);
+            fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(cur.j0), min(kTile, cur.je - cur.j0), tid);
         }
 
         while (cur.q < q_end) {
             {
                 const int j0 = cur.j0;
-                if (GATHER_NOW) gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
-                const int n = (GATHER || GATHER_NOW) ? gn : min(kTileX, cur.je - j0);
+                if (GATHER_NOW) gnext = gather_tile<kCols, kThreads, kTile>(rg, M, q_end, split, ns, cur, tid, gcols, gn, pieces);
+                const int n = (GATHER || GATHER_NOW) ? gn : min(kTile, cur.je - j0);
                 const int npad = (n + 31) & ~31;
                 TileCursor nxt = cur;   // the tile after this one
                 if (GATHER || GATHER_NOW) {
                     nxt = gnext;
                 } else {
-                    nxt.j0 += kTileX;
+                    nxt.j0 += kTile;
                     if (nxt.j0 >= nxt.je) {
                         nxt.q += SPARSE ? ns : 1;
                         open_interval<SPARSE, PRE>(rg, M, q_end, split, ns, nxt);
@@ -323,12 +328,12 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 }
                 if (GATHER) {
                     if (nxt.q < q_end) {
-                        gnext = gather_tile<kCols, kThreads>(rg, M, q_end, split, ns, nxt, tid, gcols, gn, pieces);
+                        gnext = gather_tile<kCols, kThreads, kTile>(rg, M, q_end, split, ns, nxt, tid, gcols, gn, pieces);
                         fetch_gathered();
                     }
                 } else if (PRE) {
                     if (nxt.q < q_end)
-                        fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(nxt.j0), min(kTileX, nxt.je - nxt.j0), tid);
+                        fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(nxt.j0), min(kTile, nxt.je - nxt.j0), tid);
                 } else if (GATHER_NOW) {
 #pragma unroll
                     for (int k = 0; k < kCols; ++k) {
@@ -433,7 +438,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
-    __shared__ uint4 tileX[kTileX * 4];
+    __shared__ uint4 tileX[fwd_tile(NW) * 4];
     int bx, b, split;
     workgroup_coords(sp, bx, b, split);
     softmin_fwd_x32_body<D, T, SPARSE, RT, NW, PRE>(prm, rg, N, M, sp, pk, bx, b, split, tileX);

@@ -173,6 +173,31 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     assert relerr(gx.cpu().numpy()[live], refg[live]) < 5e-6
 
 
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("half", [False, True])
+def test_softmin_block_sparse_small_row_blocks(cuda, D, half):
+    """Row blocks of ~30 points (the reference's ~2000 clusters on clouds of up to 1e5 points): the forward kernel runs as 2-wavefront
+    workgroups over gathered 256-column tiles (glhip_launch.h: launch_softmin_mfma; glhip_softmin_x32.h: fwd_tile), packed on the fly
+    and from pre-packed records; fp32 and bf16 clouds, with and without column splits, against the C oracle on the same ranges."""
+    rng = np.random.default_rng(41 + D)
+    N, M = 2300, 2600
+    x, y, h = _clouds(43, N, M, D)
+    rg, tup, _, keep, ri = _random_ranges(rng, N, M, 80, 90, 0.3, cuda)
+    assert N // 80 <= 64
+    xt, yt = _t(x, cuda), _t(y, cuda)
+    if half:
+        xt, yt = xt.bfloat16(), yt.bfloat16()
+        x, y = xt.float().cpu().numpy(), yt.float().cpu().numpy()
+    eps = 0.02
+    ref = oracle_c.softmin(eps, x, y, h, 2, ranges=tup)
+    live = np.isfinite(ref)
+    assert (~live).sum() == ri[0, 1] - ri[0, 0]          # the row block with nothing to reduce over
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_PREPACK | hip.FLAG_NO_SPLIT):
+        out = hip.softmin(eps, xt, yt, _t(h, cuda), p=2, ranges=rg, flags=flags).cpu().numpy()
+        assert np.isposinf(out[~live]).all(), flags
+        assert np.abs(out[live] - ref[live]).max() < 1.2e-6 + 2e-6 * np.abs(ref[live]).max(), flags
+
+
 def test_softmin_block_sparse_prepacked_path(cuda):
     """>= 5e8 nominal pairs: the block-sparse launch copies pre-packed column records (global centre, per-column layout,
     tiles starting at arbitrary columns) instead of packing per workgroup.  Against the oracle and the 16x16x32 kernel."""

@@ -26,14 +26,14 @@ for sub in ("pmc_util", "pmc_inst", "pmc_wait", "pmc_pipe", "pmc_fetch", "pmc_wr
     for db in glob.glob("$OUT/" + sub + "/**/*.db", recursive=True):
         c = sqlite3.connect(db)
         for k, cn, n, avg, dur in c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"):
-            if "glhip::" in k and dur > 5e6:
+            if "glhip::" in k and dur > float("${MIN_NS:-5e6}"):
                 vals[k][cn] = avg; vals[k]["_ns"] = dur
-print("## PMC per launch (kernels longer than 5 ms); pairs per launch = 1e12")
+print("## PMC per launch (kernels longer than ${MIN_NS:-5e6} ns); pairs per launch = ${PAIRS:-1e12}")
 for k, d in sorted(vals.items(), key=lambda kv: -kv[1]["_ns"]):
     ms = d["_ns"] / 1e6
     line = f"{ms:8.2f} ms  " + "  ".join(f"{n}={v:.4g}" for n, v in sorted(d.items()) if n != "_ns")
     if "SQ_INSTS_VALU" in d:
-        line += f"  | VALU wave-instr per 64 pairs = {d['SQ_INSTS_VALU'] / (1e12 / 64):.2f}"
+        line += f"  | VALU wave-instr per 64 pairs = {d['SQ_INSTS_VALU'] / (${PAIRS:-1e12} / 64):.2f}"
     if "GRBM_GUI_ACTIVE" in d:
         line += f"  clock = {d['GRBM_GUI_ACTIVE'] / 8.0 / d['_ns']:.2f} GHz"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
