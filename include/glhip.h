@@ -76,6 +76,8 @@ extern "C" {
 
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
+ *   GLHIP_FWD_NW2_ROWS = R    block-sparse forward launches whose row blocks hold up to R points on average run as 2-wavefront
+ *                             workgroups over 256-column tiles (default 64; 0: never)
  *   GLHIP_ITER4_PRE_MIN = <p> glhip_sinkhorn_iter4 pre-packs the columns of its problems from <p> pairs per launch on (default 1e8)
  *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
  *                             on explicit differences (default 2^-8; 1e30 = every pair, used by the tests to check the register
