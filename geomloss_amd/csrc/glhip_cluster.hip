@@ -230,9 +230,18 @@ struct KeepRule {
 
 __device__ __forceinline__ bool keep_pair(const KeepRule& k, int i, int j) {
     float d2 = 0.f;
-    for (int d = 0; d < k.D; ++d) {
-        const float t = k.rows[(long)i * k.D + d] - k.cols[(long)j * k.D + d];
-        d2 = __builtin_fmaf(t, t, d2);
+    if (k.D <= 3) {      // branch-free: the loads of several calls can be in flight together (runs_kernel)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int dd = d < k.D ? d : 0;
+            const float t = k.rows[(long)i * k.D + dd] - k.cols[(long)j * k.D + dd];
+            d2 = d < k.D ? __builtin_fmaf(t, t, d2) : d2;
+        }
+    } else {
+        for (int d = 0; d < k.D; ++d) {
+            const float t = k.rows[(long)i * k.D + d] - k.cols[(long)j * k.D + d];
+            d2 = __builtin_fmaf(t, t, d2);
+        }
     }
     if (k.kind == GLHIP_KEEP_WITHIN) return d2 <= k.thr;                       // kernel_samples.py:244-252
     const float C = (k.p == 2) ? 0.5f * d2 : sqrtf(fmaxf(d2, 1e-8f));          // cost_routines, sinkhorn_samples.py:26-29
@@ -255,34 +264,51 @@ __global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int n_starts = 0, n_stops = 0;
     int prev_keep = 0, prev_end = -1;     // column c0 - 1 (wave-uniform)
-    for (int c0 = 0; c0 < Cc; c0 += 64) {
-        const int c = c0 + lane;
-        const int k = (c < Cc && keep_pair(rule, i, c)) ? 1 : 0;
-        const int cs = c < Cc ? ranges_cols[2 * c] : -2, ce = c < Cc ? ranges_cols[2 * c + 1] : -3;
-        int kl = __shfl_up(k, 1, 64), el = __shfl_up(ce, 1, 64);
-        if (lane == 0) { kl = prev_keep; el = prev_end; }
-        int kr = __shfl_down(k, 1, 64), sr = __shfl_down(cs, 1, 64);
-        if (lane == 63) {   // the right neighbour lives in the next chunk
-            kr = (c + 1 < Cc && keep_pair(rule, i, c + 1)) ? 1 : 0;
-            sr = c + 1 < Cc ? ranges_cols[2 * (c + 1)] : -4;
+    // four 64-column steps per round: the loads behind their keep tests are independent and in flight together (a wavefront per
+    // row cluster is a latency-bound walk: 27-47 us per launch over ~2000 x 2000 clusters with one step per round)
+    constexpr int U = 4;
+    for (int c0 = 0; c0 < Cc; c0 += 64 * U) {
+        int k[U + 1], cs[U + 1], ce[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 64 * u + lane, cc = min(c, Cc - 1);      // unconditional loads, masked afterwards
+            const int kk = keep_pair(rule, i, cc) ? 1 : 0, s0 = ranges_cols[2 * cc], e0 = ranges_cols[2 * cc + 1];
+            k[u] = c < Cc ? kk : 0;
+            cs[u] = c < Cc ? s0 : -2;
+            ce[u] = c < Cc ? e0 : -3;
         }
-        const bool start = k && !(kl && el == cs);
-        const bool stop = k && !(kr && sr == ce);
-        const unsigned long long ms = __ballot(start), me = __ballot(stop);
-        if (FILL) {
-            if (start) {
-                const int slot = base + n_starts + __popcll(ms & below);
-                if (slot < capacity) red[2 * slot] = cs; else *overflow = 1;
-            }
-            if (stop) {
-                const int slot = base + n_stops + __popcll(me & below);
-                if (slot < capacity) red[2 * slot + 1] = ce; else *overflow = 1;
-            }
+        {   // lane 0 of the next round, for the right neighbour of the last lane
+            const int c = c0 + 64 * U, cc = min(c, Cc - 1);
+            const int kk = keep_pair(rule, i, cc) ? 1 : 0, s0 = ranges_cols[2 * cc];
+            k[U] = c < Cc ? kk : 0;
+            cs[U] = c < Cc ? s0 : -4;
         }
-        n_starts += __popcll(ms);
-        n_stops += __popcll(me);
-        prev_keep = __shfl(k, 63, 64);
-        prev_end = __shfl(ce, 63, 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + 64 * u >= Cc) break;      // wave-uniform
+            int kl = __shfl_up(k[u], 1, 64), el = __shfl_up(ce[u], 1, 64);
+            if (lane == 0) { kl = prev_keep; el = prev_end; }
+            int kr = __shfl_down(k[u], 1, 64), sr = __shfl_down(cs[u], 1, 64);
+            const int kn = __shfl(k[u + 1], 0, 64), sn = __shfl(cs[u + 1], 0, 64);     // first column of the next step
+            if (lane == 63) { kr = kn; sr = sn; }
+            const bool start = k[u] && !(kl && el == cs[u]);
+            const bool stop = k[u] && !(kr && sr == ce[u]);
+            const unsigned long long ms = __ballot(start), me = __ballot(stop);
+            if (FILL) {
+                if (start) {
+                    const int slot = base + n_starts + __popcll(ms & below);
+                    if (slot < capacity) red[2 * slot] = cs[u]; else *overflow = 1;
+                }
+                if (stop) {
+                    const int slot = base + n_stops + __popcll(me & below);
+                    if (slot < capacity) red[2 * slot + 1] = ce[u]; else *overflow = 1;
+                }
+            }
+            n_starts += __popcll(ms);
+            n_stops += __popcll(me);
+            prev_keep = __shfl(k[u], 63, 64);
+            prev_end = __shfl(ce[u], 63, 64);
+        }
     }
     if (!FILL && lane == 0) counts[i] = n_starts;
 }
@@ -293,12 +319,25 @@ __global__ void __launch_bounds__(256) kept_pairs_kernel(KeepRule rule, int Cr, 
                                                          const int32_t* __restrict__ ranges_cols, unsigned long long* __restrict__ kept) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= Cr) return;
+    const int ii = i < Cr ? i : Cr - 1;
     long long cols = 0;
-    for (int c = lane; c < Cc; c += 64)
-        if (keep_pair(rule, i, c)) cols += ranges_cols[2 * c + 1] - ranges_cols[2 * c];
+    for (int c0 = 0; c0 < Cc; c0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 64 * u + lane, cc = min(c, Cc - 1);      // unconditional loads, masked afterwards
+            const int len = ranges_cols[2 * cc + 1] - ranges_cols[2 * cc];
+            cols += (keep_pair(rule, ii, cc) && c < Cc) ? len : 0;
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) cols += __shfl_xor(cols, off, 64);
-    if (lane == 0 && cols > 0) atomicAdd(kept, (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * i + 1] - ranges_rows[2 * i]));
+    __shared__ unsigned long long part[4];
+    part[threadIdx.x >> 6] = (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * ii + 1] - ranges_rows[2 * ii]);   // rows beyond Cr: not summed below
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 4 && blockIdx.x * 4 + w < Cr; ++w) t += part[w];
+        if (t) atomicAdd(kept, t);
+    }
 }
 
 // inclusive scan of `counts` (n <= a few 1e5) by a single workgroup -> CSR end offsets
