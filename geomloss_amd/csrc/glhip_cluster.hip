@@ -334,9 +334,23 @@ __global__ void __launch_bounds__(256) kept_pairs_kernel(KeepRule rule, int Cr, 
     part[threadIdx.x >> 6] = (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * ii + 1] - ranges_rows[2 * ii]);   // rows beyond Cr: not summed below
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < 4 && blockIdx.x * 4 + w < Cr; ++w) t += part[w];
+        unsigned long long t = 0, sq = 0;
+        for (int w = 0; w < 4 && blockIdx.x * 4 + w < Cr; ++w) {
+            t += part[w];
+            const unsigned long long n = (unsigned long long)(ranges_rows[2 * (blockIdx.x * 4 + w) + 1] - ranges_rows[2 * (blockIdx.x * 4 + w)]);
+            sq += n * n;
+        }
         if (t) atomicAdd(kept, t);
+        atomicAdd(kept + 1, sq);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {      // the same statistic of the column clusters, once
+        unsigned long long sq = 0;
+        for (int c = lane; c < Cc; c += 64) {
+            const unsigned long long m = (unsigned long long)(ranges_cols[2 * c + 1] - ranges_cols[2 * c]);
+            sq += m * m;
+        }
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if (lane == 0) kept[2] = sq;
     }
 }
 
@@ -455,7 +469,7 @@ int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols
     if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_block_ranges_kept_pairs: p must be 1 or 2");
     if (!kept) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL kept");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    (void)hipMemsetAsync(kept, 0, sizeof(long long), st);
+    (void)hipMemsetAsync(kept, 0, 3 * sizeof(long long), st);
     if (Cr == 0 || Cc == 0) return GLHIP_OK;
     if (!rows || !cols || !ranges_rows || !ranges_cols || (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
         return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL pointer");

@@ -45,6 +45,7 @@ struct Scratch {
     size_t bytes;
     bool allow_split;
     bool force_pre;     // GLHIP_FLAG_PREPACK
+    bool small_rows;    // GLHIP_FLAG_SMALL_ROW_BLOCKS
     ChunkBuf cb;        // block-sparse launches: room for the row-chunk table, carved off the front of the workspace
     // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
     // GLHIP_FLAG_NO_SPLIT tells us to leave alone
@@ -58,7 +59,8 @@ struct Scratch {
 // Scratch of one API call.  Block-sparse calls reserve the front of the workspace for the row-chunk table (sized for the
 // smallest row tile, 128 rows); the rest serves the column splits and the packed columns as before.
 Scratch make_scratch(void* workspace, size_t bytes, int flags, int n_ranges, int N) {
-    Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0, ChunkBuf()};
+    Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0,
+               (flags & GLHIP_FLAG_SMALL_ROW_BLOCKS) != 0, ChunkBuf()};
     if (n_ranges > 0 && workspace) {
         const size_t need = chunk_table_bytes(n_ranges, N, 128);
         if (bytes >= need) {
@@ -212,12 +214,13 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     // block-sparse with row blocks of a few hundred points (multiscale at 1e6: 0.27 vs 0.30 s); 4 wavefronts when
     // every workgroup packs its own tiles or the row blocks are small, where more, smaller workgroups win.
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
-    static const int small_rows = getenv("GLHIP_FWD_NW2_ROWS") ? atoi(getenv("GLHIP_FWD_NW2_ROWS")) : 64;
     if (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
-    else if (KIND == FWD_X32 && n_ranges > 0 && !forced_nw && N / n_ranges <= small_rows)
-        // row blocks of up to 64 points (the reference's ~2000 clusters on clouds of up to ~1.4e5 points): 2 wavefronts x 256-column
-        // tiles — in a 4-wavefront workgroup half the wavefronts would own no row and only stage and wait
+    else if (KIND == FWD_X32 && n_ranges > 0 && sc.small_rows && !forced_nw)
+        // the caller says the pairs sit in row blocks of up to 64 points (GLHIP_FLAG_SMALL_ROW_BLOCKS): 2 wavefronts x 256-column
+        // tiles — in a 4-wavefront workgroup half the wavefronts would own no row and only stage and wait.  Not inferred from the
+        // MEAN block (N / n_ranges): clusters of a cloud sampled on a surface average 47 points at N = 1e5 while most pairs
+        // belong to blocks of hundreds, which 64-row workgroups cut into twice the chunks (measured: 12.2 -> 18.1 ms per loss)
         launch_softmin_mfma_nw<D, T, FWD_X32, 2>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (forced_nw ? forced_nw == 8
                        : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libgeomloss_hip.so")
 GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
-FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST = 1, 2, 4, 8, 16, 32, 64
+FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST, FLAG_SMALL_ROW_BLOCKS = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
 XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussian product run on the matrix cores up to this dimension
 
@@ -155,13 +155,19 @@ class BlockRanges:
     (``_legacy/sinkhorn_samples.py:515``); ``.t()`` is ``swap_axes`` (``:529``).
     """
 
-    def __init__(self, ranges_i, slices_i, redranges_j, ranges_j, slices_j, redranges_i):
+    def __init__(self, ranges_i, slices_i, redranges_j, ranges_j, slices_j, redranges_i, small_i=False, small_j=False):
         self.ranges_i, self.slices_i, self.redranges_j = ranges_i, slices_i, redranges_j
         self.ranges_j, self.slices_j, self.redranges_i = ranges_j, slices_j, redranges_i
+        # launch hints (GLHIP_FLAG_SMALL_ROW_BLOCKS): the pairs of this orientation / of the transposed one sit in row blocks of
+        # up to 64 points.  Set by whoever knows the block sizes (sinkhorn_samples.kernel_truncation); results do not depend on them.
+        self.small_i, self.small_j = bool(small_i), bool(small_j)
 
     def t(self):
         return BlockRanges(self.ranges_j, self.slices_j, self.redranges_i,
-                           self.ranges_i, self.slices_i, self.redranges_j)
+                           self.ranges_i, self.slices_i, self.redranges_j, self.small_j, self.small_i)
+
+    def launch_flags(self):
+        return FLAG_SMALL_ROW_BLOCKS if self.small_i else 0
 
     def c_args(self):
         n = int(self.ranges_i.shape[0])
@@ -170,6 +176,10 @@ class BlockRanges:
 
 
 _NO_RANGES = [None, None, None, 0]
+
+
+def _range_flags(flags, ranges):
+    return int(flags) | (0 if ranges is None else ranges.launch_flags())
 
 
 def _range_args(ranges, B):
@@ -221,7 +231,7 @@ def softmin_fwd_raw(x, y, h, eps, p=2, ranges=None, flags=0):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
         rc = lib.glhip_softmin_fwd(x.data_ptr(), y.data_ptr(), h.data_ptr(), out.data_ptr(), B, N, M, D,
                                    float(eps), int(p), _dtype_code(x), *_range_args(ranges, B), *ws_args,
-                                   int(flags), _stream(x))
+                                   _range_flags(flags, ranges), _stream(x))
     _check(rc, lib)
     return out
 
@@ -237,7 +247,7 @@ def sinkhorn_step_raw(x, y, logw, pot, prev, eps, damping, p=2, ranges=None, fla
         rc = lib.glhip_sinkhorn_step(x.data_ptr(), y.data_ptr(), logw.data_ptr(),
                                      None if pot is None else pot.data_ptr(), None if prev is None else prev.data_ptr(),
                                      out.data_ptr(), B, N, M, D, float(eps), float(damping), int(p), _dtype_code(x),
-                                     *_range_args(ranges, B), *ws_args, int(flags), _stream(x))
+                                     *_range_args(ranges, B), *ws_args, _range_flags(flags, ranges), _stream(x))
     _check(rc, lib)
     return out
 
@@ -446,17 +456,18 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
 
 
 def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
-    """Pairs of points the keep rule of :func:`block_ranges_raw` retains (``glhip_block_ranges_kept_pairs``; same arguments): one
-    launch and one 8-byte read-back, no intervals built."""
+    """``(kept pairs of points, sum of squared row-cluster sizes, sum of squared column-cluster sizes)`` for the keep rule of
+    :func:`block_ranges_raw` (``glhip_block_ranges_kept_pairs``; same arguments): one launch and one 24-byte read-back, no intervals
+    built."""
     lib = load_library()
     Cr, D = rows.shape
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     with torch.cuda.device(rows.device):
-        kept = torch.empty(1, dtype=torch.int64, device=rows.device)
+        kept = torch.empty(3, dtype=torch.int64, device=rows.device)
         _check(lib.glhip_block_ranges_kept_pairs(int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, cols.shape[0], D, int(p),
                                                  float(thr), ranges_rows.data_ptr(), ranges_cols.data_ptr(), kept.data_ptr(),
                                                  _stream(rows)), lib)
-    return int(kept.item())
+    return tuple(int(v) for v in kept.tolist())
 
 
 # ----------------------------------------------------------------------------------------------

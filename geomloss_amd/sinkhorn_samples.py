@@ -361,13 +361,21 @@ def dense_is_cheaper(kept, N, M, Cr, Cc):
     return sparse > float(N) * float(M)
 
 
+# rows of a 2-wavefront workgroup of the block-sparse soft-min (GLHIP_FLAG_SMALL_ROW_BLOCKS); GEOMLOSS_HIP_SMALL_ROW_BLOCK=0: never hint
+_SMALL_ROW_BLOCK = int(os.environ.get("GEOMLOSS_HIP_SMALL_ROW_BLOCK", "64"))
+
+
 def _goes_dense(truncate, eps, eps_last, N, M, Cr, Cc, kept_pairs):
-    """`kept_pairs`: callable, the read-back is only paid where the switch may apply."""
+    """``(dense, small_rows, small_cols)``.  `kept_pairs`: callable -> (kept pairs, sum of squared row-cluster sizes, of column-cluster
+    sizes); the read-back is only paid where the switch may apply.  small_*: the block a typical PAIR lives in (sum of squares /
+    points — not the mean cluster: a cloud sampled on a surface has clusters of 47 points on average at N = 1e5 and most of its pairs
+    in clusters of hundreds) has at most 64 points, the launch hint of hip.BlockRanges."""
     if _DENSE_SWITCH == "always":
-        return True
+        return True, False, False
     if _DENSE_SWITCH == "0" or eps_last is None or truncate * eps / eps_last < _DENSE_SWITCH_MIN_EXPONENT:
-        return False
-    return dense_is_cheaper(kept_pairs(), N, M, Cr, Cc)
+        return False, False, False
+    kept, sq_rows, sq_cols = kept_pairs()
+    return dense_is_cheaper(kept, N, M, Cr, Cc), sq_rows <= _SMALL_ROW_BLOCK * N, sq_cols <= _SMALL_ROW_BLOCK * M
 
 
 def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False, eps_last=None):
@@ -383,8 +391,11 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
     if native_p is not None and native_clustering_applies(x):
         rule = ("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps)
-        dense = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], lambda: kept_pairs_device(*rule, p=native_p))
+        dense, small_x, small_y = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0],
+                                              lambda: kept_pairs_device(*rule, p=native_p))
         ranges_xy_ = None if dense else block_ranges_device(*rule, p=native_p)
+        if ranges_xy_ is not None:
+            ranges_xy_.small_i, ranges_xy_.small_j = small_x, small_y
         if verbose:     # the printed statistic only: the ranges above are the ones a silent run builds (same kernels either way)
             with torch.no_grad():
                 C = cost(x, y)
@@ -403,11 +414,14 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
         def kept_pairs():
             rows = (ranges_x[:, 1] - ranges_x[:, 0]).double()
             cols = (ranges_y[:, 1] - ranges_y[:, 0]).double()
-            return float(rows @ (keep.double() @ cols))
+            return tuple(torch.stack([rows @ (keep.double() @ cols), rows @ rows, cols @ cols]).tolist())
 
-        if x_.is_cuda and _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], kept_pairs):
+        dense, small_x, small_y = (_goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0], kept_pairs)
+                                   if x_.is_cuda else (False, False, False))
+        if dense:
             return (x_, yd_, None, None, None), (y_, xd_, None, None, None)
         ranges_xy_ = from_matrix(ranges_x, ranges_y, keep)
+        ranges_xy_.small_i, ranges_xy_.small_j = small_x, small_y
     return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
 
 

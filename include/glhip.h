@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 109 /* 0.1.9 */
+#define GLHIP_VERSION 110 /* 0.1.10 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -73,11 +73,12 @@ extern "C" {
                                  the matrix cores, centred on each row block (glhip_dist_x32.h).  2-3x fewer VALU instructions; accurate
                                  (~2^-24 (rho + d)^2 / d on a potential, rho = row-block diameter) when row blocks are spatially compact:
                                  the caller's responsibility (voxel clusters of the multiscale backends, voxel-sorted dense clouds). */
+#define GLHIP_FLAG_SMALL_ROW_BLOCKS 128 /* block-sparse soft-min forward / half-step, D <= 3: the pairs sit in row blocks of up to 64 points
+                                  (sum of squared block sizes / N <= 64): launch 2-wavefront workgroups over 256-column tiles.  A hint: results
+                                  do not depend on it.  The caller knows the block sizes (glhip_block_ranges_kept_pairs returns the sum). */
 
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
- *   GLHIP_FWD_NW2_ROWS = R    block-sparse forward launches whose row blocks hold up to R points on average run as 2-wavefront
- *                             workgroups over 256-column tiles (default 64; 0: never)
  *   GLHIP_ITER4_PRE_MIN = <p> glhip_sinkhorn_iter4 pre-packs the columns of its problems from <p> pairs per launch on (default 1e8)
  *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
  *                             on explicit differences (default 2^-8; 1e30 = every pair, used by the tests to check the register
@@ -328,9 +329,11 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
                              int32_t* slices_rows, int32_t* slices_cols, int32_t* totals, void* stream);
 
 /* Pairs of POINTS the keep rule of glhip_block_ranges retains (same arguments), without building the intervals:
- * kept (1) int64 out = sum over the kept cluster pairs (i, j) of |rows_i| x |cols_j|.  The reference prints this figure at the level
- * of clusters when verbose (sinkhorn_samples.py:516-522); the host side costs a block-sparse fine level against a dense one with it
- * BEFORE building the pattern (geomloss_amd/sinkhorn_samples.py: kernel_truncation; `truncate=None` at :504-505 is the dense one). */
+ * kept (3) int64 out = { sum over the kept cluster pairs (i, j) of |rows_i| x |cols_j|,  sum_i |rows_i|^2,  sum_j |cols_j|^2 }.
+ * The reference prints the first figure at the level of clusters when verbose (sinkhorn_samples.py:516-522); the host side costs a
+ * block-sparse fine level against a dense one with it BEFORE building the pattern (geomloss_amd/sinkhorn_samples.py:
+ * kernel_truncation; `truncate=None` at :504-505 is the dense one).  The other two give the size of the block a typical PAIR lives in
+ * (sum of squares / number of points), which is what GLHIP_FLAG_SMALL_ROW_BLOCKS is set from. */
 int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc,
                                   int D, int p, float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, long long* kept,
                                   void* stream);

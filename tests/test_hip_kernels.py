@@ -183,7 +183,7 @@ def test_softmin_block_sparse_small_row_blocks(cuda, D, half):
     N, M = 2300, 2600
     x, y, h = _clouds(43, N, M, D)
     rg, tup, _, keep, ri = _random_ranges(rng, N, M, 80, 90, 0.3, cuda)
-    assert N // 80 <= 64
+    rg.small_i = True          # the launch hint kernel_truncation sets (GLHIP_FLAG_SMALL_ROW_BLOCKS); blocks of up to ~150 rows are fine too
     xt, yt = _t(x, cuda), _t(y, cuda)
     if half:
         xt, yt = xt.bfloat16(), yt.bfloat16()

@@ -452,14 +452,18 @@ def test_dense_switch_cost_model_and_exponent_gate():
     old = ss._DENSE_SWITCH
     try:
         ss.set_dense_switch("1")
-        assert not ss._goes_dense(5, 0.108, 0.05, 10_000, 10_000, 2000, 2000, never)           # p = 1: 5 x 2.2 < 16
-        assert not ss._goes_dense(2, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never)     # truncate = 2
-        assert not ss._goes_dense(5, eps_jump, None, 10_000, 10_000, 2000, 2000, never)         # a caller that does not say
-        assert ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, lambda: 0.21e8)
-        assert not ss._goes_dense(5, eps_jump, eps_last, 100_000, 100_000, 2170, 2170, lambda: 0.21e10)
+        no = (False, False, False)
+        assert ss._goes_dense(5, 0.108, 0.05, 10_000, 10_000, 2000, 2000, never) == no           # p = 1: 5 x 2.2 < 16
+        assert ss._goes_dense(2, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never) == no     # truncate = 2
+        assert ss._goes_dense(5, eps_jump, None, 10_000, 10_000, 2000, 2000, never) == no         # a caller that does not say
+        assert ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, lambda: (0.21e8, 5e4, 5e4))[0]
+        # 1e5 points: the pattern stays; uniform clusters of 46 points take the small-row-block launch, a cloud whose pairs sit in
+        # clusters of hundreds does not, whatever the mean cluster is
+        assert ss._goes_dense(5, eps_jump, eps_last, 100_000, 100_000, 2170, 2170, lambda: (0.21e10, 47e5, 48e5)) == (False, True, True)
+        assert ss._goes_dense(5, eps_jump, eps_last, 100_000, 100_000, 2170, 2170, lambda: (0.21e10, 300e5, 60e5)) == (False, False, True)
         ss.set_dense_switch("0")
-        assert not ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never)
+        assert ss._goes_dense(5, eps_jump, eps_last, 10_000, 10_000, 2000, 2000, never) == no
         ss.set_dense_switch("always")
-        assert ss._goes_dense(2, eps_jump, None, 10, 10, 2, 2, never)
+        assert ss._goes_dense(2, eps_jump, None, 10, 10, 2, 2, never) == (True, False, False)
     finally:
         ss.set_dense_switch(old)

@@ -464,7 +464,8 @@ def test_dense_fine_level_where_cheaper(cuda, monkeypatch):
         sl, red = rg.slices_i.cpu().numpy(), rg.redranges_j.cpu().numpy().astype(np.int64)
         want = sum(int(ri[i, 1] - ri[i, 0]) * int((red[(sl[i - 1] if i else 0):sl[i], 1] - red[(sl[i - 1] if i else 0):sl[i], 0]).sum())
                    for i in range(37))
-        assert 0 < want < 5000 * 4000 and kept_pairs_device(*rule, p=p) == want
+        sq_i, sq_j = int(((ri[:, 1] - ri[:, 0]).astype(np.int64) ** 2).sum()), int(((rj[:, 1] - rj[:, 0]).astype(np.int64) ** 2).sum())
+        assert 0 < want < 5000 * 4000 and kept_pairs_device(*rule, p=p) == (want, sq_i, sq_j)
 
     g = torch.Generator().manual_seed(8)
     x, y = torch.rand(6000, 4, generator=g).to(cuda), torch.rand(5000, 4, generator=g).to(cuda)
@@ -484,3 +485,18 @@ def test_dense_fine_level_where_cheaper(cuda, monkeypatch):
     del launches[:]
     SamplesLoss("sinkhorn", p=1, blur=0.05, backend="multiscale")(x[:, :3].contiguous(), y[:, :3].contiguous())
     assert any(launches)                                                      # p = 1 keeps its pattern
+
+    # 6e4 uniform points in 3-D: the pattern stays (21 % kept, clusters of 27 points) and its launches carry the small-row-block hint
+    # (2-wavefront workgroups); same loss as the dense fine level
+    monkeypatch.setattr(hip, "softmin", real)
+    monkeypatch.setattr(hip, "sinkhorn_step", real_step)
+    x3, y3 = torch.rand(60_000, 3, generator=g).to(cuda), torch.rand(60_000, 3, generator=g).to(cuda)
+    hinted = []
+    real_raw = hip.sinkhorn_step_raw
+    monkeypatch.setattr(hip, "sinkhorn_step_raw", lambda *a, **k: (hinted.append(
+        None if (k.get("ranges") if "ranges" in k else a[8]) is None else (k.get("ranges") if "ranges" in k else a[8]).launch_flags()), real_raw(*a, **k))[1])
+    L1 = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")(x3, y3).item()
+    assert hip.FLAG_SMALL_ROW_BLOCKS in hinted
+    monkeypatch.setattr(ss, "_DENSE_SWITCH", "always")
+    L2 = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")(x3, y3).item()
+    assert abs(L1 - L2) < 1e-5 * abs(L2)
