@@ -454,9 +454,15 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
     // 4 wavefronts x 1 tile, more workgroups
     constexpr int NM = XdShape<D>::NM;
     const bool big = (double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192);
-    if (big) {
-        if (NM <= 4 || (NM == 5 && n_ranges == 0)) launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
-        else launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    if (big) {      // (constexpr where the shape decides: the configurations a dimension never takes are not compiled)
+        if constexpr (NM <= 4) {
+            launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+        } else if constexpr (NM == 5) {
+            if (n_ranges == 0) launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            else launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+        } else {
+            launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+        }
     } else {
         launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
     }
