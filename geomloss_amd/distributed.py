@@ -41,8 +41,12 @@ def global_diameter(x, y, group=None):
     """Bounding-box diagonal of the union of all ranks' (flattened) clouds: 2 all-reduces of D floats."""
     D = x.shape[-1]
     xf, yf = x.reshape(-1, D), y.reshape(-1, D)
-    mins = torch.minimum(xf.min(dim=0)[0], yf.min(dim=0)[0]).float()
-    maxs = torch.maximum(xf.max(dim=0)[0], yf.max(dim=0)[0]).float()
+    if xf.shape[0] == 0 or yf.shape[0] == 0:     # a rank without batch items (B < world size): neutral for MIN / MAX
+        mins = torch.full((D,), float("inf"), device=x.device)
+        maxs = torch.full((D,), float("-inf"), device=x.device)
+    else:
+        mins = torch.minimum(xf.min(dim=0)[0], yf.min(dim=0)[0]).float()
+        maxs = torch.maximum(xf.max(dim=0)[0], yf.max(dim=0)[0]).float()
     dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=group)
     return (maxs - mins).norm().item()
@@ -73,7 +77,10 @@ class ShardedSamplesLoss(torch.nn.Module):
         if getattr(loss, "diameter", None) is None and getattr(loss, "loss", None) == "sinkhorn":
             loss = copy.copy(loss)  # same schedule on every rank as the unsharded reference computation
             loss.diameter = global_diameter(x.detach(), y.detach(), self.group)
-        local = loss(*args)  # (B_local,)
+        if x.shape[0] == 0:      # nothing on this rank: it still takes part in the collectives above and below
+            local = x.new_zeros(0, dtype=torch.float32) + 0.0 * x.sum()
+        else:
+            local = loss(*args)  # (B_local,)
 
         if self.reduction == "none":
             sizes = [torch.zeros(1, dtype=torch.long, device=local.device) for _ in range(dist.get_world_size(self.group))]

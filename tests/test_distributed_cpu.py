@@ -64,6 +64,50 @@ def test_sharded_loss_equals_unsharded_world2():
         assert rel_total < 1e-6 and gerr < 1e-6 and verr < 1e-6 and merr < 1e-6
 
 
+def _worker_short_batch(rank, world, port, q):
+    """B = 1 on two ranks: rank 1 owns no item and must still take part in every collective."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geomloss_amd import SamplesLoss
+        from geomloss_amd.distributed import ShardedSamplesLoss, shard_batch
+
+        torch.manual_seed(1)
+        x, y = torch.rand(1, 30, 3), torch.rand(1, 35, 3)
+        base = SamplesLoss("sinkhorn", p=2, blur=0.1, backend="tensorized")
+        full = base(x, y)
+        xl = shard_batch(x).clone().requires_grad_(True)
+        yl = shard_batch(y)
+        total = ShardedSamplesLoss(base, "sum")(xl, yl)
+        (g,) = torch.autograd.grad(total, [xl])
+        vec = ShardedSamplesLoss(base, "none")(xl.detach(), yl)
+        mean = ShardedSamplesLoss(base, "mean")(xl.detach(), yl)
+        ok_grad = g.shape == xl.shape and (rank == 1 or float(g.abs().sum()) > 0)
+        q.put((rank, xl.shape[0], float((total - full.sum()).abs()), float((vec - full).abs().max()), float((mean - full.mean()).abs()),
+               ok_grad, None))
+    except Exception as e:
+        q.put((rank, None, None, None, None, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loss_with_a_rank_that_owns_nothing():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_short_batch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[1] for r in results) == [0, 1]
+    for rank, _, terr, verr, merr, ok_grad, err in results:
+        assert err is None, f"rank {rank}: {err}"
+        assert terr < 1e-7 and verr < 1e-7 and merr < 1e-7 and ok_grad
+
+
 def test_shard_bounds_partition_the_batch():
     from geomloss_amd.distributed import shard_bounds
     for B in (1, 7, 8, 256):
