@@ -329,7 +329,7 @@ def clusterize(a, x, scale=None, labels=None):
 # below ~3e4 points a cluster holds a handful of them and a block-sparse launch fills a fraction of its 32-row tiles (N = 1e4, D = 3:
 # 99 us per soft-min against 10 us for the dense kernel on the same points); and labels that leave a coordinate out (the reference's
 # 4-D recipe clusters the 3 spatial coordinates of position + feature points) give clusters as wide as the cloud, of which the rule
-# keeps 86 %.  Before the pattern is built the pairs its rule keeps are counted (one launch, one 8-byte read-back) and costed against
+# keeps 86 %.  Before the pattern is built the pairs its rule keeps are counted (one launch, one 24-byte read-back) and costed against
 # the dense launch:
 #     block-sparse ~ kept / (kDenseRate * fill),   fill = filled share of the 32-row tiles of a mean cluster,   dense ~ N M
 # and the cheaper one runs — the fine level of `truncate=None` (``:504-505``).  Only where that cannot move a result: a dropped
