@@ -320,6 +320,54 @@ def sharded_reference(dev, B=256, reps=3):
             "pairs_per_s": cfg4_pairs(B) / t, "loss_sum": float(L)}
 
 
+def settle_host():
+    """One full Python garbage collection now, survivors moved out of the collector's reach (``gc.freeze``).  Why this is part of
+    the protocol: the first generation-2 collection of a process that has imported torch walks ~1e6 objects and takes 30-40 ms
+    (measured: profiles/r05_shard_stall.txt); it fires once, a few thousand allocations in — inside the timed region or not, by luck —
+    and while the host is stopped the launch queue of a 2 ms step drains.  That was the "B = 32 anomaly" of the round-4 review."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
+def shard_curve(dev, sizes=(256, 128, 64, 32), calls=200):
+    """What one rank of `--gpus W` computes per step, for W = 256 / B, measured on THIS GPU: B problems of BASELINE configs[3],
+    every call bracketed by HIP events on the launch stream.  median / p99 / max per call + the share of the ideal (B / 256 of the
+    B = 256 median) — the single-GPU evidence behind the 1 -> 8 curve (no collective is on the data path)."""
+    from geomloss_amd import SamplesLoss
+
+    loss = SamplesLoss("sinkhorn", backend="online", **CFG4)
+    out = {"workload": "SamplesLoss('sinkhorn', online) forward, B x 4096 x 4096 3D bf16, diameter=1.8; per-call HIP-event times", "calls": calls,
+           "shards": {}}
+    for B in sizes:
+        x, y = cfg4_batch(dev, B, seed=2)
+        for _ in range(5):
+            loss(x, y).sum()
+        settle_host()
+        torch.cuda.synchronize()
+        a = [torch.cuda.Event(enable_timing=True) for _ in range(calls)]
+        b = [torch.cuda.Event(enable_timing=True) for _ in range(calls)]
+        t0 = time.perf_counter()
+        for k in range(calls):
+            a[k].record()
+            loss(x, y).sum()
+            b[k].record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / calls * 1e3
+        ms = sorted(s.elapsed_time(e) for s, e in zip(a, b))
+        med = ms[len(ms) // 2]
+        out["shards"][str(B)] = {"gpus_equivalent": 256 / B, "median_ms": med, "p99_ms": ms[min(calls - 1, int(0.99 * calls))], "max_ms": ms[-1],
+                                 "wall_ms_per_call": wall, "stalls_over_1p3x_median": sum(1 for t in ms if t > 1.3 * med),
+                                 "pairs_per_s_at_median": cfg4_pairs(B) / (med * 1e-3)}
+        log(f"[bench] shard_curve B={B}: median {med:.3f} ms, p99 {out['shards'][str(B)]['p99_ms']:.3f}, max {ms[-1]:.3f}, wall {wall:.3f} ms/call")
+    if "256" in out["shards"]:
+        full = out["shards"]["256"]["median_ms"]
+        for B in sizes:
+            r = out["shards"][str(B)]
+            r["share_of_ideal"] = full * B / 256 / r["median_ms"]
+    return out
+
+
 def run_headline(args, dev):
     from geomloss_amd import hip
 
@@ -327,6 +375,7 @@ def run_headline(args, dev):
     x, y, h, eps = make_problem(n, dev, seed=1000)
     for _ in range(args.warmup):
         hip.softmin_fwd_raw(x, y, h, eps, 2)
+    settle_host()
     torch.cuda.synchronize()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -393,7 +442,7 @@ def run_headline(args, dev):
                 log(f"[bench] HBM traffic of the dominant kernel (PMC, this run): {t['bytes_per_launch'] / 1e6:.0f} MB per launch")
         for key, fn in (("kernels", lambda: hot_path_kernels(dev, n)), ("cpu_baseline", cpu_baseline),
                         ("sinkhorn_wallclock", lambda: sinkhorn_wallclock(dev)),
-                        ("sharded_batch_reference", lambda: sharded_reference(dev))):
+                        ("sharded_batch_reference", lambda: sharded_reference(dev)), ("shard_curve", lambda: shard_curve(dev))):
             try:
                 res[key] = fn()
             except Exception as e:   # never lose the GPU number to a side leg
@@ -423,6 +472,7 @@ def run_sharded(args, dev, rank, world):
 
     for _ in range(args.warmup):
         loss(x, y)
+    settle_host()          # the process's one 30-40 ms full garbage collection happens here, not inside a 2 ms step
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -466,7 +516,9 @@ def run_sharded(args, dev, rank, world):
                 "pairs_per_step": pairs, "global_batch": B,
                 "parallelism": f"batch sharded x{world} (contiguous slices), no data-path collective, one scalar all-reduce per step "
                                f"({args.backend})",
-                "single_gpu_point": "`sharded_batch_reference` of the N=1 line (same workload, whole batch on one GPU)",
+                "single_gpu_point": "`sharded_batch_reference` of the N=1 line (same workload, whole batch on one GPU); per-shard "
+                                    "timings of one GPU: `shard_curve` of the same line",
+                "protocol": "W warm-up steps, one full Python garbage collection + gc.freeze (settle_host), barrier, K timed steps, barrier",
             },
             "loss_sum": float(total),
             "per_rank_ms": [r["local_loss_ms"] for r in sorted(per_rank, key=lambda r: r["rank"])],

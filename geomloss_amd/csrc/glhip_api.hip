@@ -32,7 +32,7 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         if (n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8)    // forward, big dense launches: up to 32 splits (one split's records per XCD L2) + the pre-packed column records
             bytes = (size_t)32 * (size_t)B * (size_t)N * 2 * sizeof(float) + 256 + (size_t)B * (size_t)((M + 31) / 32) * 32 * (size_t)(2 * ((6 * (D + 1) + 15) / 16)) * sizeof(uint4);   // XdShape<D>::NBP records per column
         bytes = bytes > grad ? bytes : grad;
-        if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);
+        if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 64);
         return bytes;
     }
     const long row_blocks = n_ranges > 0 ? n_ranges : (long)B * ((N + 2 * kBlock - 1) / (2 * kBlock));
@@ -71,7 +71,7 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
                           (size_t)B * (size_t)((M + 31) / 32) * 2048 + (size_t)4 * B * M * sizeof(float);
         bytes = bytes > ws ? bytes : ws;
     }
-    if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 128);   // row-chunk table of block-sparse launches
+    if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 64);   // row-chunk table of block-sparse launches (64-row tiles: the smallest, GLHIP_FLAG_SMALL_ROW_BLOCKS)
     return bytes;
 }
 

@@ -57,18 +57,24 @@ struct Scratch {
 };
 
 // Scratch of one API call.  Block-sparse calls reserve the front of the workspace for the row-chunk table (sized for the
-// smallest row tile, 128 rows); the rest serves the column splits and the packed columns as before.
+// smallest row tile of the call: 128 rows, 64 under GLHIP_FLAG_SMALL_ROW_BLOCKS); the rest serves the column splits and the packed
+// columns as before.
 Scratch make_scratch(void* workspace, size_t bytes, int flags, int n_ranges, int N) {
     Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0,
                (flags & GLHIP_FLAG_SMALL_ROW_BLOCKS) != 0, ChunkBuf()};
     if (n_ranges > 0 && workspace) {
-        const size_t need = chunk_table_bytes(n_ranges, N, 128);
-        if (bytes >= need) {
-            sc.cb.buf = static_cast<int32_t*>(workspace);
-            sc.cb.capacity = (long)n_ranges + N / 128 + 1;
-            sc.ws = static_cast<char*>(workspace) + need;
-            sc.bytes = bytes - need;
-            if (sc.bytes == 0) sc.ws = nullptr;
+        // 64-row workgroups (GLHIP_FLAG_SMALL_ROW_BLOCKS) cut a cluster into twice as many chunks: their table is sized for 64-row tiles
+        // (glhip_workspace_bytes reserves that much for every block-sparse call); with less workspace, the 128-row table.
+        for (int rows = sc.small_rows ? 64 : 128; rows <= 128; rows *= 2) {
+            const size_t need = chunk_table_bytes(n_ranges, N, rows);
+            if (bytes >= need) {
+                sc.cb.buf = static_cast<int32_t*>(workspace);
+                sc.cb.capacity = (long)n_ranges + N / rows + 1;
+                sc.ws = static_cast<char*>(workspace) + need;
+                sc.bytes = bytes - need;
+                if (sc.bytes == 0) sc.ws = nullptr;
+                break;
+            }
         }
     }
     return sc;

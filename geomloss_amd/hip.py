@@ -112,16 +112,19 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def _points(t, name):
-    """Point clouds go to the kernels as contiguous fp32, bf16 or fp64; other float types are widened / narrowed to fp32.
-    float64 clouds keep their dtype — the reference's matrix-free backends do (``_legacy/sinkhorn_samples.py:229-290``) — and run
-    on the double-precision kernels (``glhip_*_f64``: no matrix cores, ~20x slower than fp32; cast to fp32 for speed)."""
+def _points(t, name, allow_f64=False):
+    """Point clouds go to the kernels as contiguous fp32 or bf16 — or, from the four entry points that have double-precision kernels
+    (``allow_f64``: soft-min, its gradient, kernel product, its gradient), as fp64; every other float type is widened / narrowed
+    to fp32.  float64 clouds keep their dtype there — the reference's matrix-free backends do (``_legacy/sinkhorn_samples.py:229-290``)
+    — and run on ``glhip_*_f64`` (any D; no matrix cores, ~20x slower than fp32: cast to fp32 for speed).  The fp32-only entry points
+    (one-launch iteration, one-pass value + gradient, hard C-transform) never see an fp64 buffer: a launch with dtype code F32 on
+    doubles would read garbage silently (round-4 advice)."""
     if not t.is_cuda:
         raise RuntimeError(
             f"geomloss_amd: '{name}' lives on {t.device}; the HIP backends ('online', 'multiscale') need GPU tensors. "
             "Use backend='tensorized' for CPU tensors."
         )
-    if t.dtype not in (torch.float32, torch.bfloat16, torch.float64):
+    if t.dtype not in ((torch.float32, torch.bfloat16, torch.float64) if allow_f64 else (torch.float32, torch.bfloat16)):
         t = t.float()
     return t.contiguous()
 
@@ -589,6 +592,8 @@ def compact_rows_plan(x, y, ranges=None, flags=0):
     builds the plan once and passes it down (``_HipSoftmin`` in sinkhorn_samples.py does, for the ~40 reductions of a Sinkhorn
     loop); one-off calls of :func:`softmin` / :func:`kernel_conv` build their own — two sorts of ~1 ms against a reduction
     of ~0.2 s at the sizes where plans apply."""
+    if is_f64(x):       # double-precision clouds run on glhip_*_f64, which take no plan
+        return None
     xb = _points(x.detach(), "x")
     yb = _points(y.detach(), "y")
     xb, yb = (xb.unsqueeze(0) if xb.dim() == 2 else xb), (yb.unsqueeze(0) if yb.dim() == 2 else yb)
@@ -617,7 +622,7 @@ class _Softmin(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, h, eps, p, ranges, flags, plan=None):
-        xb, yb, hb, batched = _as_batched(_points(x, "x"), _points(y, "y"), h.detach().contiguous())
+        xb, yb, hb, batched = _as_batched(_points(x, "x", True), _points(y, "y", True), h.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         plan = _plan_for(plan, xb, yb, ranges, flags) if (p == 1 and not is_f64(xb)) else None
@@ -909,7 +914,7 @@ class _KernelConv(torch.autograd.Function):
     def product(kind, x, y, v, blur, ranges, flags, want_unit):
         """The launch behind forward: (xb, yb, vb, batched, out (B,N), unit (B,N,D) | None); unit_i = d out_i / d x_i when
         ``want_unit`` and a product-and-gradient kernel exists for this kind and dimension."""
-        xb, yb, vb, batched = _as_batched(_points(x, "x"), _points(y, "y"), v.detach().contiguous())
+        xb, yb, vb, batched = _as_batched(_points(x, "x", True), _points(y, "y", True), v.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         if is_f64(xb):      # double precision: the plain product kernel, no plans, no fused gradient
@@ -1051,7 +1056,7 @@ def kernel_conv_row_gradient(kind, x, y, v, g, blur, flags=0):
     """No autograd: d/dx of sum_i g_i (K v)_i as one gradient reduction (``glhip_kernel_conv_bwd_x``), shaped like x."""
     kind = KERNEL_KINDS[kind] if isinstance(kind, str) else int(kind)
     with torch.no_grad():
-        xb, yb, vb, _ = _as_batched(_points(x, "x"), _points(y, "y"), v.detach().contiguous())
+        xb, yb, vb, _ = _as_batched(_points(x, "x", True), _points(y, "y", True), v.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         gb = _vec(g, xb).reshape(xb.shape[0], -1)
@@ -1155,6 +1160,17 @@ def max_lines(g, step, p=2):
 
 def lse_lines(h, eps, p=2):
     return _LseLines.apply(h, float(eps), int(p))
+
+
+def settle_host():
+    """For latency-critical loops (serving, benchmarks): one full Python garbage collection now, and its survivors moved out of the
+    collector's reach (``gc.freeze()``).  The first generation-2 collection of a process that has imported torch walks ~1e6 objects
+    and takes 30-40 ms; it fires once, a few thousand container allocations in, wherever the program happens to be — and while the
+    host is stopped the launch queue of a 2 ms loss drains and the GPU idles (measured: profiles/r05_shard_stall.txt; this was the
+    intermittent 2x outlier of the B = 32 shard of BASELINE configs[3]).  Call it after the warm-up of such a loop; bench.py does."""
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 # ----------------------------------------------------------------------------------------------

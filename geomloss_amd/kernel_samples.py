@@ -244,12 +244,12 @@ class _UnionNorm(torch.autograd.Function):
         gl = gL.reshape(-1, 1) if batch else gL.reshape(())
         s = 1.0 / (blur * blur)
         z = torch.cat((x, y.to(x.dtype)), dim=-2)
-        w = torch.cat((α, -β), dim=-1).to(z.dtype)
+        w = torch.cat((α, -β), dim=-1).to(_weights_dtype(x))      # fp32 next to bf16 / fp16 clouds, like forward and _backward_once
         D = x.shape[-1]
 
         def rows(pts, wt, U):            # wt_i sum_j w_j grad_1 k(pts_i, z_j) = -s wt_i [ pts_i U_i - (K (w z))_i ]
-            Kwz = torch.stack([hip.kernel_conv(name, pts, z, w * z[..., d], blur) for d in range(D)], dim=-1)
-            return (gl * wt).unsqueeze(-1) * (-s) * (pts * U.unsqueeze(-1) - Kwz)
+            Kwz = torch.stack([hip.kernel_conv(name, pts, z, w * z[..., d].to(w.dtype), blur) for d in range(D)], dim=-1)
+            return (gl * wt.to(w.dtype)).unsqueeze(-1) * (-s) * (pts.to(w.dtype) * U.unsqueeze(-1) - Kwz)
         U_x = hip.kernel_conv(name, x, z, w, blur)
         U_y = hip.kernel_conv(name, y, z, w, blur)
         gα = gl * U_x if ctx.needs_input_grad[2] else None
@@ -278,10 +278,11 @@ def _kernel_loss_union(α, x, β, y, blur, name, potentials):
                 return 0.5 * scal_sum(α, U_x, β, -U_y, batch=batch)
         return _UnionNorm.apply(name, 1.0 if blur is None else float(blur), α, x, β, y)
 
-    # potentials (``:139-141``): rows of x, rows of y; each differentiates through its own rows only, with a doubled gradient
-    # (``:117-125`` plays the same trick on K_xx and K_yy); the columns and their weights are constants
-    U_x = hip.kernel_conv(name, double_grad(x), z, w, blur)      # (k*α - k*β)(x_i)
-    U_y = hip.kernel_conv(name, double_grad(y), z, w, blur)      # (k*α - k*β)(y_j)
+    # potentials (``:139-141``) that nobody differentiates (kernel_loss sends the others to the four products of the reference):
+    # rows of x, rows of y of the same signed product
+    with torch.no_grad():
+        U_x = hip.kernel_conv(name, x, z, w, blur)      # (k*α - k*β)(x_i)
+        U_y = hip.kernel_conv(name, y, z, w, blur)      # (k*α - k*β)(y_j)
     return U_x, -U_y
 
 
@@ -293,7 +294,11 @@ def kernel_loss(
     HIP path (the keyword keeps the reference's name; no KeOps is involved)."""
     batch = x.dim() > 2
     if use_keops and kernel is None and ranges_xx is None and ranges_yy is None and ranges_xy is None:
-        return _kernel_loss_union(α, x, β, y, blur, name, potentials)
+        # Potentials that somebody differentiates keep the reference's four products (below): F = K(2x, x̄) ᾱ - K(x, y) β is
+        # differentiable once in x through the self term and in x, y AND β through the cross term (``:117-141``), a structure the
+        # union form — all columns and weights constants — cannot reproduce (round-4 advice: ∂F/∂y, ∂F/∂β, ∂G/∂x, ∂G/∂α came out zero).
+        if not potentials or _takes_no_gradient(α, x, β, y):
+            return _kernel_loss_union(α, x, β, y, blur, name, potentials)
 
     K_xx, K_yy, K_xy = _kernel_operators(x, y, blur, kernel, name, use_keops, (ranges_xx, ranges_yy, ranges_xy))
 

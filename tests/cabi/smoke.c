@@ -1,0 +1,179 @@
+/*
+ * tests/cabi/smoke.c — a caller of libgeomloss_hip.so that is NOT geomloss_amd/hip.py: plain C, the prototypes of
+ * include/glhip.h as the compiler sees them, device memory from hipMalloc, no Python, no torch.
+ *
+ * Every other test reaches the library through the ctypes signature table of hip.py; a wrong `argtypes` entry there and a wrong
+ * prototype here cannot agree with each other by accident, so this program pins the header itself (round-4 review, weak #9).
+ * It plays the reference's call sites for the path: `lse_genred(...)(x, y, h, 1/eps)` (_legacy/sinkhorn_samples.py:322-346),
+ * `keops_lse(..., ranges=...)` (:432-450), KeOps `Grad` of the last soft-min, and `K @ v` (kernel_samples.py:117-137).
+ *
+ * Checker: the C restatement of the oracle (oracle/oracle_c.c, linked as liboracle_c.so) on the same doubles-of-floats.
+ * TEST INFRASTRUCTURE: built by __graft_entry__.build() (tests/cabi/Makefile), run by tests/test_cabi_gpu.py on the GPU box.
+ * Prints one line per check and exits non-zero on the first failure.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "glhip.h"
+
+/* oracle/oracle_c.c */
+void oracle_softmin(const double* x, const double* y, const double* h, double* out, int N, int M, int D, double eps, int p,
+                    const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges);
+void oracle_softmin_grad_x(const double* x, const double* y, const double* h, const double* g, double* gx, int N, int M, int D,
+                           double eps, int p, const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j,
+                           int n_ranges);
+void oracle_kconv(int kind, const double* x, const double* y, const double* v, double* out, int N, int M, int D, double blur,
+                  const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges);
+
+#define HIP_OK(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+            exit(2);                                                                                 \
+        }                                                                                            \
+    } while (0)
+#define GL_OK(call)                                                                                  \
+    do {                                                                                             \
+        int rc_ = (call);                                                                            \
+        if (rc_ != GLHIP_OK) {                                                                       \
+            fprintf(stderr, "glhip error %d (%s) at %s:%d\n", rc_, glhip_last_error(), __FILE__, __LINE__); \
+            exit(3);                                                                                 \
+        }                                                                                            \
+    } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static double uniform(void) { /* xorshift64*: deterministic, no libc rand */
+    rng_state ^= rng_state >> 12;
+    rng_state ^= rng_state << 25;
+    rng_state ^= rng_state >> 27;
+    return (double)((rng_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
+}
+static double normal(void) { return sqrt(-2.0 * log(1.0 - uniform())) * cos(6.283185307179586 * uniform()); }
+
+static void* to_device(const void* src, size_t bytes) {
+    void* p = NULL;
+    HIP_OK(hipMalloc(&p, bytes ? bytes : 4));
+    if (bytes) HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return p;
+}
+
+static int failures = 0;
+static void report(const char* what, double err, double tol) {
+    printf("%-58s err %.3e  (tol %.1e)  %s\n", what, err, tol, err < tol ? "ok" : "FAIL");
+    if (!(err < tol)) ++failures;
+}
+static double max_abs(const float* got, const double* want, size_t n, int relative) {
+    double e = 0.0, s = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+        if (isinf(want[k]) && isinf((double)got[k]) && (want[k] > 0) == (got[k] > 0)) continue;
+        const double d = fabs((double)got[k] - want[k]);
+        if (!(d <= e)) e = d; /* NaN counts */
+        if (fabs(want[k]) > s && !isinf(want[k])) s = fabs(want[k]);
+    }
+    return relative ? e / (s > 0 ? s : 1.0) : e;
+}
+
+int main(void) {
+    enum { N = 700, M = 900, D = 3 };
+    const float eps = 0.05f * 0.05f, blur = 0.2f;
+    int n_dev = 0;
+    HIP_OK(hipGetDeviceCount(&n_dev));
+    if (n_dev < 1) { fprintf(stderr, "no GPU\n"); return 2; }
+    HIP_OK(hipSetDevice(0));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    printf("glhip_version() = %d (header GLHIP_VERSION = %d)\n", glhip_version(), GLHIP_VERSION);
+    if (glhip_version() != GLHIP_VERSION) { fprintf(stderr, "header / library version mismatch\n"); return 4; }
+
+    /* inputs: floats on the device, the same values as doubles for the oracle */
+    static float xf[N * D], yf[M * D], hf[M], gf[N], vf[M];
+    static double xd[N * D], yd[M * D], hd[M], gd[N], vd[M];
+    for (int k = 0; k < N * D; ++k) xd[k] = xf[k] = (float)uniform();
+    for (int k = 0; k < M * D; ++k) yd[k] = yf[k] = (float)(0.1 + 0.8 * uniform());
+    for (int k = 0; k < M; ++k) hd[k] = hf[k] = (float)(normal() - log((double)M));
+    for (int k = 0; k < N; ++k) gd[k] = gf[k] = (float)normal();
+    for (int k = 0; k < M; ++k) vd[k] = vf[k] = (float)(uniform() / M) * ((k % 7) ? 1.f : -1.f);
+    hd[11] = hf[11] = -INFINITY; /* a column without mass */
+    void *x = to_device(xf, sizeof xf), *y = to_device(yf, sizeof yf);
+    float *h = to_device(hf, sizeof hf), *g = to_device(gf, sizeof gf), *v = to_device(vf, sizeof vf);
+    float *out = to_device(NULL, N * sizeof(float)), *gx = to_device(NULL, N * D * sizeof(float));
+    static float out_h[N], gx_h[N * D];
+    static double ref[N], refg[N * D];
+
+    const size_t ws_bytes = glhip_workspace_bytes(1, N, M, D, 0);
+    void* ws = to_device(NULL, ws_bytes);
+
+    /* 1. dense soft-min, p = 2 and p = 1 (lse_genred, sinkhorn_samples.py:322-346) */
+    for (int p = 2; p >= 1; --p) {
+        const float e = p == 2 ? eps : 0.05f;
+        GL_OK(glhip_softmin_fwd(x, y, h, out, 1, N, M, D, e, p, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpy(out_h, out, sizeof out_h, hipMemcpyDeviceToHost));
+        oracle_softmin(xd, yd, hd, ref, N, M, D, (double)e, p, NULL, NULL, NULL, 0);
+        report(p == 2 ? "glhip_softmin_fwd dense p=2" : "glhip_softmin_fwd dense p=1", max_abs(out_h, ref, N, 0), 3e-6);
+    }
+
+    /* 2. its row gradient (KeOps Grad of the last soft-min, sinkhorn_divergence.py:612-623) */
+    GL_OK(glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 2, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream));
+    GL_OK(glhip_softmin_bwd_x(x, y, h, out, g, gx, 1, N, M, D, eps, 2, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(gx_h, gx, sizeof gx_h, hipMemcpyDeviceToHost));
+    oracle_softmin_grad_x(xd, yd, hd, gd, refg, N, M, D, (double)eps, 2, NULL, NULL, NULL, 0);
+    report("glhip_softmin_bwd_x dense p=2 (relative, max-norm)", max_abs(gx_h, refg, N * D, 1), 2e-5);
+
+    /* 3. block-sparse soft-min (keops_lse with ranges, sinkhorn_samples.py:432-450): 3 row blocks; the second keeps nothing */
+    {
+        const int32_t ranges_i[6] = {0, 250, 250, 300, 300, N}, slices_i[3] = {2, 2, 3}, red[6] = {0, 100, 400, 650, 500, M};
+        int32_t *ri = to_device(ranges_i, sizeof ranges_i), *si = to_device(slices_i, sizeof slices_i), *rj = to_device(red, sizeof red);
+        const size_t wsb = glhip_workspace_bytes(1, N, M, D, 3);
+        void* wsr = to_device(NULL, wsb);
+        GL_OK(glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 2, GLHIP_F32, ri, si, rj, 3, wsr, wsb, 0, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpy(out_h, out, sizeof out_h, hipMemcpyDeviceToHost));
+        oracle_softmin(xd, yd, hd, ref, N, M, D, (double)eps, 2, ranges_i, slices_i, red, 3);
+        report("glhip_softmin_fwd block-sparse (one empty row block)", max_abs(out_h, ref, N, 0), 3e-6);
+        int inf_rows = 0;
+        for (int i = 250; i < 300; ++i) inf_rows += isinf(out_h[i]) && out_h[i] > 0;
+        report("   rows of the empty block are +inf (missing of 50)", (double)(50 - inf_rows), 0.5);
+        HIP_OK(hipFree(ri)); HIP_OK(hipFree(si)); HIP_OK(hipFree(rj)); HIP_OK(hipFree(wsr));
+    }
+
+    /* 4. kernel products K @ v (kernel_samples.py:117-137) */
+    for (int kind = GLHIP_GAUSSIAN; kind <= GLHIP_ENERGY; ++kind) {
+        GL_OK(glhip_kernel_conv_fwd(kind, x, y, v, out, 1, N, M, D, blur, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpy(out_h, out, sizeof out_h, hipMemcpyDeviceToHost));
+        oracle_kconv(kind, xd, yd, vd, ref, N, M, D, (double)blur, NULL, NULL, NULL, 0);
+        char name[64];
+        snprintf(name, sizeof name, "glhip_kernel_conv_fwd kind=%d (relative, max-norm)", kind);
+        report(name, max_abs(out_h, ref, N, 1), 1e-4);
+    }
+
+    /* 5. no workspace at all (NULL, 0) is legal: same answer */
+    GL_OK(glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 2, GLHIP_F32, NULL, NULL, NULL, 0, NULL, 0, 0, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(out_h, out, sizeof out_h, hipMemcpyDeviceToHost));
+    oracle_softmin(xd, yd, hd, ref, N, M, D, (double)eps, 2, NULL, NULL, NULL, 0);
+    report("glhip_softmin_fwd without workspace", max_abs(out_h, ref, N, 0), 3e-6);
+
+    /* 6. error paths: code + thread-local message, nothing thrown across the ABI */
+    {
+        int rc = glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 3, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream);
+        printf("p = 3            -> rc %d, \"%s\"\n", rc, glhip_last_error());
+        report("unsupported exponent returns GLHIP_EUNSUPPORTED", rc == GLHIP_EUNSUPPORTED ? 0.0 : 1.0, 0.5);
+        rc = glhip_softmin_fwd(NULL, y, h, out, 1, N, M, D, eps, 2, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream);
+        printf("x = NULL         -> rc %d, \"%s\"\n", rc, glhip_last_error());
+        report("NULL cloud returns GLHIP_EINVAL with a message", (rc == GLHIP_EINVAL && strlen(glhip_last_error()) > 0) ? 0.0 : 1.0, 0.5);
+        rc = glhip_softmin_fwd(x, y, h, out, 1, N, M, D, -1.f, 2, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream);
+        report("eps <= 0 returns GLHIP_EINVAL", rc == GLHIP_EINVAL ? 0.0 : 1.0, 0.5);
+    }
+
+    HIP_OK(hipStreamDestroy(stream));
+    printf(failures ? "C-ABI smoke: %d FAILED\n" : "C-ABI smoke: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}

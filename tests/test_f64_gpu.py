@@ -26,7 +26,7 @@ def _clouds(seed, N, M, D, B=None):
     return rng.random(shp(N)), rng.random(shp(M)) * 0.8 + 0.1, rng.standard_normal(shp(M)[:-1])
 
 
-@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 9, 16])
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 9, 16, 17, 20, 37])       # D > 16: f64_generic_kernel (round 5)
 @pytest.mark.parametrize("p", [2, 1])
 def test_f64_softmin_and_gradient_vs_c_oracle(cuda, D, p):
     N, M = 300, 1000
@@ -48,7 +48,7 @@ def test_f64_softmin_and_gradient_vs_c_oracle(cuda, D, p):
 
 
 @pytest.mark.parametrize("kind", ["gaussian", "laplacian", "energy"])
-@pytest.mark.parametrize("D", [2, 3, 6])
+@pytest.mark.parametrize("D", [2, 3, 6, 20])
 def test_f64_kernel_products_and_gradients_vs_c_oracle(cuda, kind, D):
     B, N, M = 2, 260, 700
     x, y, v = _clouds(D, N, M, D, B=B)
@@ -114,3 +114,31 @@ def test_f64_multiscale_matches_the_two_scale_oracle(cuda):
     assert L.dtype == torch.float64 and abs(L.item() - ref) / abs(ref) < 1e-8
     (gx,) = torch.autograd.grad(L, [xt])
     assert relerr(gx.cpu().numpy(), ref_gx) < 1e-7
+
+
+def test_f64_clouds_of_dimension_20_keep_their_dtype_end_to_end(cuda):
+    """float64 clouds with D > 16 through ``SamplesLoss`` on the online backend (round-4 advice: they raised GLHIP_EUNSUPPORTED):
+    loss and gradient in float64, against the NumPy oracle; and a block-sparse launch of the generic-D float64 kernel."""
+    rng = np.random.default_rng(5)
+    N, M, D = 250, 320, 20
+    x, y = rng.random((N, D)) * 0.5, rng.random((M, D)) * 0.5 + 0.1
+    for name, kw in (("sinkhorn", dict(p=2, blur=0.3)), ("gaussian", dict(blur=0.4)), ("energy", dict())):
+        xt = _t(x, cuda).requires_grad_(True)
+        L = SamplesLoss(name, backend="online", **kw)(xt, _t(y, cuda))
+        (gx,) = torch.autograd.grad(L, [xt])
+        assert L.dtype == torch.float64 and gx.dtype == torch.float64
+        if name == "sinkhorn":
+            ref, rgx, _ = oracle_np.sinkhorn_loss_and_grad(x, y, **kw)
+        else:
+            ref, rgx = oracle_np.kernel_loss(name, x, y, **kw), oracle_np.kernel_loss_grad_x(name, x, y, **kw)
+        assert abs(L.item() - ref) < 1e-9 * abs(ref), name
+        assert relerr(gx.cpu().numpy(), rgx) < 1e-8, name
+    # block-sparse, D = 20: two row blocks, the first keeps both column blocks, the second only the last
+    h = rng.standard_normal(M)
+    ri = np.array([[0, 100], [100, N]], np.int32)
+    rj = np.array([[0, 150], [150, M]], np.int32)
+    keep = np.array([[True, True], [False, True]])
+    rg = from_matrix(_t(ri, cuda), _t(rj, cuda), _t(keep, cuda))
+    out = hip.softmin(0.1, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, ranges=rg).cpu().numpy()
+    assert relerr(out[:100], oracle_c.softmin(0.1, x[:100], y, h, 2)) < 1e-12
+    assert relerr(out[100:], oracle_c.softmin(0.1, x[100:], y[150:], h[150:], 2)) < 1e-12

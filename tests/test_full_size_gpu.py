@@ -129,8 +129,10 @@ def test_cfg2_online_sinkhorn_1e5_loss_potentials_gradient(cuda, shift):
           f"potentials abs {err_F:.2e} (scale {scale_F:.2e})")
     assert err_L < 1e-4
     assert err_g < 1e-4
-    # debiased potentials f_ba - f_aa are differences of raw dual values: the error is judged on the scale of those
-    assert err_F < 1e-4 * max(np.abs(ref["f_ba"]).max(), np.abs(ref["g_ab"]).max())
+    # debiased potentials f_ba - f_aa: judged on their own range
+    own_range = max(np.ptp(ref_F), np.ptp(ref_G))
+    print(f"   potentials: own range {own_range:.3e}, abs error / range {err_F / own_range:.2e}")
+    assert err_F < 1e-4 * own_range
 
 
 # ---- configs[3]: batched Sinkhorn, N = M = 4096, bf16 points ------------------------------------------------------------
@@ -247,6 +249,47 @@ def test_gradient_kernels_1e6_sampled_rows(cuda):
     assert relerr(gx[rsel].cpu().numpy(), ref) < 1e-4
 
 
+def test_headline_launch_all_rows(cuda):
+    """The EXACT launch bench.py times (``bench.make_problem(1e6, seed=1000)`` -> ``hip.softmin_fwd_raw``: pre-packed columns, 32
+    XCD-aware column splits, merge), every one of its 1e6 rows against the brute-force float64 HIP oracle (1e12 float64 pair
+    evaluations, ~4 s).  Bar: 1.5e-6 absolute on values of size 0.1 ... 1.5 (fp32 resolution of the expanded exponent, as in
+    tests/test_hip_kernels.py); measured margin in the line printed."""
+    import bench
+    from oracle import oracle_hip64
+    n = 1_000_000
+    x, y, h, eps = bench.make_problem(n, cuda, seed=1000)
+    out = hip.softmin_fwd_raw(x, y, h, eps, 2)
+    assert out.shape == (1, n) and bool(torch.isfinite(out).all())
+    ref = oracle_hip64.softmin(eps, x[0], y[0], h[0], 2, device=cuda)
+    err = (out[0].double() - ref).abs()
+    worst = int(err.argmax())
+    print(f"headline launch, all {n} rows: max abs error {err.max().item():.3e} (row {worst}, value {ref[worst].item():.6f}), "
+          f"mean abs error {err.mean().item():.3e}, value range [{ref.min().item():.4f}, {ref.max().item():.4f}]")
+    assert err.max().item() < 1.5e-6
+
+
+def test_cfg4_whole_batch_256_through_the_sharded_loss(cuda):
+    """BASELINE configs[3] as bench.py runs it — B = 256 problems of 4096 x 4096 bf16 points through ``ShardedSamplesLoss`` (world
+    size 1: the whole batch on this GPU, the launch plan of ``sharded_batch_reference``) — every item's loss against the float64
+    oracle on the bf16-rounded points, and the ``loss_sum`` that the bench line prints."""
+    import bench
+    from geomloss_amd.distributed import ShardedSamplesLoss
+    B = 256
+    x, y = bench.cfg4_batch(cuda, B, seed=2)
+    inner = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)
+    per_item = inner(x, y)
+    total = ShardedSamplesLoss(inner, reduction="sum")(x, y)
+    assert per_item.shape == (B,) and abs(total.item() - per_item.sum().item()) <= 1e-6 * abs(total.item())
+    kw = {k: v for k, v in bench.CFG4.items()}
+    refs = np.array([o64.sinkhorn_loss(x[k].double(), y[k].double(), device=cuda, **kw) for k in range(B)])
+    got = per_item.double().cpu().numpy()
+    rel = np.abs(got - refs) / np.abs(refs)
+    print(f"cfg4 B=256: worst item rel {rel.max():.2e} (item {rel.argmax()}), loss_sum {total.item():.9e} oracle {refs.sum():.9e} "
+          f"rel {abs(total.item() - refs.sum()) / abs(refs.sum()):.2e}")
+    assert rel.max() < 1e-4
+    assert abs(total.item() - refs.sum()) < 1e-4 * abs(refs.sum())
+
+
 # ---- configs[2]: the block-sparse kernels at N = M = 1e6 with the ranges kernel truncation really produces ------------------
 
 def test_block_sparse_fwd_bwd_1e6_with_real_truncation_ranges(cuda):
@@ -325,9 +368,9 @@ def test_cfg3_multiscale_1e6_end_to_end(cuda, kind):
     """BASELINE configs[2] at its stated size, N = M = 1e6: device cluster pyramid, fused coarse loop, kernel truncation,
     extrapolation, block-sparse fine loop, one-pass final update — loss, dL/dx and potentials against ONE run of the float64
     two-scale oracle (fine level in runs of row clusters on this GPU: ~2.4e12 float64 pair evaluations).
-    ``shift``: a transport problem (y = 0.6 y + 0.3), everything at 1e-4.  ``same``: the config as benchmarked — two samples of
-    one law, whose loss (2.5e-6) is what is left of dual terms of size 0.1: potentials and gradient are asserted on their own
-    scale, the loss on the scale of the dual values it is a difference of; its relative error is reported."""
+    ``shift``: a transport problem (y = 0.6 y + 0.3).  ``same``: the config as benchmarked — two samples of one law, whose loss
+    (2.5e-6) is what is left of dual terms of size 1e-2.  Both: loss at 1e-4 RELATIVE TO THE LOSS, gradient at 1e-4 of its
+    max-norm, potentials at 1e-4 of their own range."""
     N = 1_000_000
     x, y = _uniform_clouds(1, N, N, cuda, shift=(kind == "shift"))
     kw = dict(p=2, blur=0.05)
@@ -347,12 +390,14 @@ def test_cfg3_multiscale_1e6_end_to_end(cuda, kind):
           f"{ref['dual_scale']:.2e}); dL/dx rel {e_g:.2e}; potentials abs {e_F:.2e}; clusters {info['n_clusters']}, jump {info['jumps']}, "
           f"kept {[round(k, 4) for k in info['kept_fraction']]}")
     assert 0 < info["kept_fraction"][0] < 0.6 and info["jumps"][0] < len(info["eps_list"]) - 1
-    assert e_F < 1e-4 * ref["dual_scale"]
+    # potentials: on their OWN range (max - min of the debiased potentials F, G the loss is an average of), not on the scale of the
+    # raw dual values; loss: BASELINE.json's bar, 1e-4 relative on the loss itself — also for `same`, whose 2.5e-6 is what is left
+    # of dual terms of size 1e-2 (measured: 3.4e-5 relative, profiles/r03_full_size_parity.txt; round-4 review, weak #1)
+    own_range = max(np.ptp(ref["F"]), np.ptp(ref["G"]))
+    print(f"   potentials: own range {own_range:.3e}, abs error / range {e_F / own_range:.2e}")
+    assert e_F < 1e-4 * own_range
     assert e_g < 1e-4
-    if kind == "shift":
-        assert e_L < 1e-4 * abs(ref["loss"])
-    else:
-        assert e_L < 1e-4 * ref["dual_scale"]          # the relative error of this 2.5e-6 residue is in the line printed above
+    assert e_L < 1e-4 * abs(ref["loss"])
 
 
 def test_cfg5_gaussian_mmd_1e6_loss_and_gradient(cuda):

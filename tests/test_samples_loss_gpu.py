@@ -500,3 +500,28 @@ def test_dense_fine_level_where_cheaper(cuda, monkeypatch):
     monkeypatch.setattr(ss, "_DENSE_SWITCH", "always")
     L2 = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")(x3, y3).item()
     assert abs(L1 - L2) < 1e-5 * abs(L2)
+
+
+@pytest.mark.parametrize("name", ["gaussian", "laplacian", "energy"])
+@pytest.mark.parametrize("batch", [False, True])
+def test_gradients_through_kernel_potentials_match_the_tensorized_backend(cuda, name, batch):
+    """``potentials=True`` on the matrix-free kernel backend under autograd (round-4 advice): F = K(2x, x̄) ᾱ - K(x, y) β is
+    differentiable in x (self term once, cross term once), in y and in β; G likewise in y, x and α
+    (``_legacy/kernel_samples.py:117-141``).  All six gradients of a random functional of (F, G) against the dense float64
+    evaluation of the same graph (the tensorized backend on float64 copies)."""
+    g = torch.Generator().manual_seed(12)
+    shp = (lambda n: (3, n, 3)) if batch else (lambda n: (n, 3))
+    N, M = 230, 310
+    x, y = torch.rand(shp(N), generator=g).to(cuda), (torch.rand(shp(M), generator=g) * 0.8 + 0.1).to(cuda)
+    a = torch.rand(shp(N)[:-1], generator=g).to(cuda)
+    b = torch.rand(shp(M)[:-1], generator=g).to(cuda)
+    a, b = a / a.sum(-1, keepdim=True), b / b.sum(-1, keepdim=True)
+    cF, cG = torch.randn(shp(N)[:-1], generator=g).to(cuda), torch.randn(shp(M)[:-1], generator=g).to(cuda)
+    res = {}
+    for backend, dt in (("online", torch.float32), ("tensorized", torch.float64)):
+        ts = [t.detach().to(dt).requires_grad_(True) for t in (a, x, b, y)]
+        F, G = SamplesLoss(name, blur=0.3, backend=backend, potentials=True)(*ts)
+        J = (F * cF.to(dt)).sum() + (G * cG.to(dt)).sum()
+        res[backend] = [F.detach(), G.detach()] + list(torch.autograd.grad(J, ts))
+    for k, (got, want) in enumerate(zip(res["online"], res["tensorized"])):
+        assert relerr(got.double().cpu().numpy(), want.cpu().numpy()) < 1e-4, ("F G dJ/da dJ/dx dJ/db dJ/dy".split()[k], name)
