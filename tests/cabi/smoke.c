@@ -58,7 +58,7 @@ static double normal(void) { return sqrt(-2.0 * log(1.0 - uniform())) * cos(6.28
 static void* to_device(const void* src, size_t bytes) {
     void* p = NULL;
     HIP_OK(hipMalloc(&p, bytes ? bytes : 4));
-    if (bytes) HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    if (bytes && src) HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));      /* src == NULL: an uninitialised buffer */
     return p;
 }
 

@@ -278,7 +278,16 @@ def test_cfg4_whole_batch_256_through_the_sharded_loss(cuda):
     x, y = bench.cfg4_batch(cuda, B, seed=2)
     inner = SamplesLoss("sinkhorn", backend="online", **bench.CFG4)
     per_item = inner(x, y)
-    total = ShardedSamplesLoss(inner, reduction="sum")(x, y)
+    import torch.distributed as dist
+    created = not dist.is_initialized()
+    if created:      # one rank, RCCL: the process group `bench.py --gpus 1 --force-sharded` builds
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=cuda)
+    try:
+        total = ShardedSamplesLoss(inner, reduction="sum")(x, y)
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
     assert per_item.shape == (B,) and abs(total.item() - per_item.sum().item()) <= 1e-6 * abs(total.item())
     kw = {k: v for k, v in bench.CFG4.items()}
     refs = np.array([o64.sinkhorn_loss(x[k].double(), y[k].double(), device=cuda, **kw) for k in range(B)])
