@@ -46,6 +46,7 @@ struct Scratch {
     bool allow_split;
     bool force_pre;     // GLHIP_FLAG_PREPACK
     bool small_rows;    // GLHIP_FLAG_SMALL_ROW_BLOCKS
+    bool h2;            // GLHIP_FLAG_F16X2: exponents from f16 x 2 pieces (glhip_softmin_xd.h) where a kernel has that layout
     ChunkBuf cb;        // block-sparse launches: room for the row-chunk table, carved off the front of the workspace
     // pre-packed column records pay for their extra launch from ~5e8 pairs on; they live in the workspace, which
     // GLHIP_FLAG_NO_SPLIT tells us to leave alone
@@ -61,7 +62,7 @@ struct Scratch {
 // columns as before.
 Scratch make_scratch(void* workspace, size_t bytes, int flags, int n_ranges, int N) {
     Scratch sc{workspace, bytes, (flags & GLHIP_FLAG_NO_SPLIT) == 0, (flags & GLHIP_FLAG_PREPACK) != 0,
-               (flags & GLHIP_FLAG_SMALL_ROW_BLOCKS) != 0, ChunkBuf()};
+               (flags & GLHIP_FLAG_SMALL_ROW_BLOCKS) != 0, (flags & GLHIP_FLAG_F16X2) != 0, ChunkBuf()};
     if (n_ranges > 0 && workspace) {
         // 64-row workgroups (GLHIP_FLAG_SMALL_ROW_BLOCKS) cut a cluster into twice as many chunks: their table is sized for 64-row tiles
         // (glhip_workspace_bytes reserves that much for every block-sparse call); with less workspace, the 128-row table.
@@ -391,10 +392,10 @@ void launch_dist_grad_d(const ConvParams<T>& prm, const Ranges& rg, int n_ranges
 constexpr int kXdMaxD = 16;
 constexpr long kXdSlots = 256 * 2;    // resident 8-wave workgroups (<= 48 KiB of LDS, <= 128 VGPRs)
 
-template <int MODE, int D, typename T, class MergeOp, int RT, int NW>
+template <int MODE, int D, typename T, class MergeOp, int RT, int NW, int L>
 void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                    int M, const Scratch& sc, hipStream_t st) {
-    using S = XdShape<D>;
+    using S = XdShape<D, L>;
     constexpr int kPart = MODE == XD_SOFTMIN ? 2 : 1;
     static_assert(MergeOp::kPartial == kPart, "partial formats differ");
     static_assert(MergeOp::kRows == 1, "the merge launch below tiles rows in blocks of kBlock");
@@ -430,52 +431,60 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
             const size_t part_bytes = (((size_t)nx * per_split) + 255) & ~(size_t)255;
             if (pre) {
                 pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
-                hipLaunchKernelGGL((xd_pack_kernel<MODE, D, T>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+                hipLaunchKernelGGL((xd_pack_kernel<MODE, D, T, L>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
                 if constexpr (NW == 8)
-                    hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+                    hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, true, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
             } else {
-                hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
+                hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
             }
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
         }
     }
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, true, RT, NW, false>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, none);
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, true, RT, NW, false, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, none);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
-        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
+        hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, false, L>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, none);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
     }
 }
 
-template <int MODE, int D, typename T, class MergeOp>
-void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N, int M,
-               const Scratch& sc, hipStream_t st) {
+template <int MODE, int D, typename T, class MergeOp, int L>
+void launch_xd_l(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N, int M,
+                 const Scratch& sc, hipStream_t st) {
     // big launches: 8 wavefronts x 2 row tiles (the two tiles share the LDS reads of a column group; 512 rows share the bf16
     // pieces of a column when they are packed on the fly) while the x-side operands of two tiles fit 128 VGPRs — 4 waves per
     // SIMD: up to 5 chained MFMAs (D <= 12) on dense launches, 4 (D <= 9) on block-sparse ones, 1 tile beyond; small launches:
     // 4 wavefronts x 1 tile, more workgroups
-    constexpr int NM = XdShape<D>::NM;
+    constexpr int NM = XdShape<D, L>::NM;
     const bool big = (double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192);
     if (big) {      // (constexpr where the shape decides: the configurations a dimension never takes are not compiled)
         if constexpr (NM <= 4) {
-            launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            launch_xd_cfg<MODE, D, T, MergeOp, 2, 8, L>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
         } else if constexpr (NM == 5) {
-            if (n_ranges == 0) launch_xd_cfg<MODE, D, T, MergeOp, 2, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
-            else launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            if (n_ranges == 0) launch_xd_cfg<MODE, D, T, MergeOp, 2, 8, L>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            else launch_xd_cfg<MODE, D, T, MergeOp, 1, 8, L>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
         } else {
-            launch_xd_cfg<MODE, D, T, MergeOp, 1, 8>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            launch_xd_cfg<MODE, D, T, MergeOp, 1, 8, L>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
         }
     } else {
-        launch_xd_cfg<MODE, D, T, MergeOp, 1, 4>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+        launch_xd_cfg<MODE, D, T, MergeOp, 1, 4, L>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
     }
 }
 
+// ... in the K layout the call asks for: bf16 x 3 (default) or f16 x 2 (GLHIP_FLAG_F16X2: the caller vouches for the range)
+template <int MODE, int D, typename T, class MergeOp>
+void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N, int M,
+               const Scratch& sc, hipStream_t st) {
+    if (sc.h2) launch_xd_l<MODE, D, T, MergeOp, XL_F16X2>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    else launch_xd_l<MODE, D, T, MergeOp, XL_BF16X3>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+}
+
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
-template <int MODE, int D, typename T, class MergeOp, int RT>
+template <int MODE, int D, typename T, class MergeOp, int RT, int L>
 void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                      int M, const Scratch& sc, hipStream_t st) {
     constexpr int kPart = (MODE == WS_GAUSS_BWD) ? D : D + 1;
@@ -501,17 +510,17 @@ void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params
             sp.n_splits = nx;
             sp.xcd_grid_x = gx;
             sp.xcd_blocks = gx * B;
-            hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
         }
     }
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, true, RT, NW>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, true, RT, NW, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
-        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     }
@@ -522,7 +531,8 @@ void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& m
                      int M, const Scratch& sc, hipStream_t st) {
     // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8 — measured 3-16 % faster
     // than 1 tile there (profiles/r03_grad_kernels_ab.txt); beyond, the x-side operands of two tiles no longer fit 128 VGPRs
-    launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1)>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    if (sc.h2) launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), XL_F16X2>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+    else launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), XL_BF16X3>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
 
 // soft-min gradient (and value + gradient) through the transposed kernel

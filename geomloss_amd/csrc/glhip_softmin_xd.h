@@ -40,10 +40,33 @@ namespace glhip {
 
 enum XdMode { XD_SOFTMIN = 0, XD_GAUSS = 1 };
 
-template <int D>
+// K layout of an exponent.
+//   XL_BF16X3 (default): every fp32 operand = three bf16 pieces, six products per coordinate (above).
+//   XL_F16X2  (GLHIP_FLAG_F16X2, round 5): every coordinate = TWO f16 pieces (hi + lo, 22 significant bits, round-to-nearest,
+//     subnormal pieces kept: |a - (hi + lo)| <= max(2^-23 |a|, 2^-25)), THREE products per coordinate — hi hi, hi lo, lo hi
+//     ([y_hi, y_lo, y_hi] against [a_hi, a_hi, a_lo]; the dropped lo lo is <= 2^-22 |a y|) — on v_mfma_f32_32x32x16_f16, which
+//     keeps subnormal inputs and accumulates like the bf16 form (tools/ubench/mfma_f16.hip, profiles/r05_ubench_mfma_f16.txt).
+//     Both sides carry sqrt(s) (the bf16 layout puts all of s on the rows): f16 has 5 exponent bits, and the products only need
+//     |sqrt(s) (x - c)| < 65504.  The scalar item keeps six slots, [H1,H2,H3,k,k,k] against [k,k,k,n1,n2,n3] with k = 8 and the
+//     three f16 pieces of H / 8 and n / 8 (33 bits, absolute floor 8 x 2^-25 = 2.4e-7 of an exponent, range |H| < 5.2e5).
+//     Chained MFMAs: ceil((3 D + 6) / 16) —
+//         D      1-3  4  5  6  7  8  9  10  11  12  13  14  15  16
+//         NM      1   2  2  2  2  2  3   3   3   3   3   3   4   4        (bf16 x 3:  2  2 3 3 3 4 4 5 5 5 6 6 6 7)
+//     and half the LDS bytes per column.  Accuracy: the cross term is good to ~2^-21 |a y| worst case (bf16 x 3: 2^-24), on top of
+//     the float32 accumulation both layouts share (ulp of the partial sums, truncated); measured next to each other in
+//     profiles/r05_f16x2_accuracy.txt.  RANGE IS THE CALLER'S VOUCH: exponents H_j, n_i beyond +-5e5 (log2 units), i.e. roughly
+//     (cloud diameter)^2 / eps > 3e5, overflow f16 — results are then inf / nan, loudly; the Python layer sets the flag from
+//     eps and the diameter it already knows.
+enum XdLayout { XL_BF16X3 = 0, XL_F16X2 = 1 };
+constexpr float kH2Floor = -5.0e5f;      // XL_F16X2: "minus infinity" of an exponent (padded / massless columns, rows that have seen none)
+constexpr float kH2Kappa = 8.0f;         // scale of the scalar item
+constexpr uint32_t kF16Kappa = 0x4800u;  // 8.0 as f16
+
+template <int D, int L = XL_BF16X3>
 struct XdShape {
-    static_assert(D >= 4 && D <= 16, "glhip_softmin_xd.h serves 4 <= D <= 16");
-    static constexpr int kSlots = 6 * (D + 1);       // scalar item (slots 0..5), then 6 slots per coordinate
+    static_assert(D >= 1 && D <= 16, "glhip_softmin_xd.h serves D <= 16");
+    static constexpr int kPer = (L == XL_F16X2) ? 3 : 6;     // K slots per coordinate
+    static constexpr int kSlots = 6 + kPer * D;      // scalar item (slots 0..5), then kPer slots per coordinate
     static constexpr int NM = (kSlots + 15) / 16;    // chained MFMAs per 32 x 32 block
     static constexpr int NBP = 2 * NM;               // records (8 slots, 16 bytes) per column in LDS: record r = slots [8 r, 8 r + 8)
     static constexpr int kTile = NBP <= 6 ? 512 : (NBP <= 10 ? 256 : 128);   // columns per LDS tile (on-the-fly staging)
@@ -70,6 +93,29 @@ __device__ __forceinline__ void split3_rn(float v, uint32_t (&p)[3]) {
 
 constexpr uint32_t kBf16One = 0x3F80u;
 
+// ---- XL_F16X2 pieces ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union Pack16h { uint4 u; f16x8 v; };
+__device__ __forceinline__ uint32_t f16_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
+// v = hi + lo (+ rest <= max(2^-23 |v|, 2^-25)); inf / nan (and |v| >= 65520, which f16 rounds to inf) stay in hi alone
+__device__ __forceinline__ void split2_h(float v, uint32_t (&p)[2]) {
+    const _Float16 hi = (_Float16)v;
+    const float hf = (float)hi;
+    const float r = (__builtin_fabsf(hf) <= 65504.f) ? v - hf : 0.f;      // exact
+    p[0] = f16_bits(hi);
+    p[1] = f16_bits((_Float16)r);
+}
+__device__ __forceinline__ void split3_h(float v, uint32_t (&p)[3]) {
+    const _Float16 hi = (_Float16)v;
+    const float hf = (float)hi;
+    const float r = (__builtin_fabsf(hf) <= 65504.f) ? v - hf : 0.f;
+    const _Float16 mid = (_Float16)r;
+    const float r2 = r - (float)mid;                                       // exact
+    p[0] = f16_bits(hi);
+    p[1] = f16_bits(mid);
+    p[2] = f16_bits((_Float16)r2);
+}
+
 // bf16 value of K slot `slot` of a column (y side) or of a row (x side): sc = pieces of the scalar item (H_j | n_i),
 // cp[d] = pieces of coordinate d.  All indices are compile-time constants after unrolling.
 template <int D, bool XSIDE>
@@ -88,9 +134,30 @@ __device__ __forceinline__ uint32_t xd_slot(int slot, const uint32_t (&sc)[3], c
 // The same from the float values themselves, splitting what the record needs when it needs it (a record touches the scalar and
 // at most three coordinates): for the row pass of the kernels, where 3 (D + 1) live piece registers next to RT x NM finished
 // operands pushed D = 16 over 128 VGPRs.
-template <int D, bool XSIDE>
+template <int D, bool XSIDE, int L = XL_BF16X3>
 __device__ __forceinline__ uint4 xd_record_of(int r, float scalar, const float (&val)[D]) {
     uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if constexpr (L == XL_F16X2) {      // scalar item [k,k,k,n1,n2,n3] | [H1,H2,H3,k,k,k], then [a_hi,a_hi,a_lo] | [y_hi,y_lo,y_hi] per coordinate
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int slot = 8 * r + k;
+            uint32_t h = 0u;
+            if (slot < 6 + 3 * D) {
+                if (slot < 6) {
+                    const bool one = XSIDE ? slot < 3 : slot >= 3;
+                    if (one) h = kF16Kappa;
+                    else { uint32_t p[3]; split3_h(scalar * (1.0f / kH2Kappa), p); h = p[XSIDE ? slot - 3 : slot]; }
+                } else {
+                    const int d = (slot - 6) / 3, t = (slot - 6) % 3;
+                    uint32_t p[2];
+                    split2_h(val[d < D ? d : 0], p);
+                    h = p[XSIDE ? (t == 2 ? 1 : 0) : (t == 1 ? 1 : 0)];
+                }
+            }
+            w[k >> 1] |= (k & 1) ? (h << 16) : h;
+        }
+        return uint4{w[0], w[1], w[2], w[3]};
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int slot = 8 * r + k;
@@ -124,8 +191,13 @@ __device__ __forceinline__ uint4 xd_record(int r, const uint32_t (&sc)[3], const
 }
 
 // x side, record 0 of lane half 0 = [1,1,1,n1,n2,n3, coordinate 0: a1, a1]: replaces n (soft-min: minus the running maximum)
+template <int L = XL_BF16X3>
 __device__ __forceinline__ uint4 xd_with_n(const uint4& rec0, float n) {
     uint32_t p[3];
+    if constexpr (L == XL_F16X2) {
+        split3_h(__builtin_fminf(__builtin_fmaxf(n, kH2Floor), -kH2Floor) * (1.0f / kH2Kappa), p);
+        return uint4{rec0.x, kF16Kappa | (p[0] << 16), p[1] | (p[2] << 16), rec0.w};
+    }
     split3_rn(n, p);
     return uint4{rec0.x, kBf16One | (p[0] << 16), p[1] | (p[2] << 16), rec0.w};
 }
@@ -133,10 +205,10 @@ __device__ __forceinline__ uint4 xd_with_n(const uint4& rec0, float n) {
 // One column as NBP records `stride` apart starting at `base`; coordinates relative to `centre`.
 //   XD_SOFTMIN: H = log2(e) h_j - s/2 |yt|^2  (h_j through dual_entry: the fused half-step adds pot_j / eps)
 //   XD_GAUSS:   H = -s/2 |yt|^2, and the weight v_j = prm.h[col] goes to *vdst
-template <int MODE, int D, typename T>
+template <int MODE, int D, typename T, int L = XL_BF16X3>
 __device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long col, bool valid, const float (&centre)[D],
                                                uint4* base, int stride, float* vdst) {
-    using S = XdShape<D>;
+    using S = XdShape<D, L>;
     float yt[D];
     float H = kNegBig, vj = 0.f;
 #pragma unroll
@@ -157,8 +229,14 @@ __device__ __forceinline__ void pack_column_xd(const SoftminParams<T>& prm, long
             vj = prm.h[col];
         }
     }
+    if constexpr (L == XL_F16X2) {      // both sides carry sqrt(s); exponents below the floor are the floor
+        const float q = __builtin_sqrtf(prm.s2);
 #pragma unroll
-    for (int r = 0; r < S::NBP; ++r) base[r * stride] = xd_record_of<D, false>(r, H, yt);      // record by record: few live pieces
+        for (int d = 0; d < D; ++d) yt[d] *= q;
+        H = __builtin_fmaxf(H, kH2Floor);
+    }
+#pragma unroll
+    for (int r = 0; r < S::NBP; ++r) base[r * stride] = xd_record_of<D, false, L>(r, H, yt);      // record by record: few live pieces
     if (MODE == XD_GAUSS) *vdst = vj;
 }
 
@@ -169,18 +247,18 @@ struct XdPacked {
     long stride;    // records per batch item = ceil(M / 32) * 32 * NBP
 };
 
-template <int MODE, int D, typename T>
+template <int MODE, int D, typename T, int L = XL_BF16X3>
 __global__ void __launch_bounds__(kBlock)
 xd_pack_kernel(SoftminParams<T> prm, int N, int M, XdPacked pk) {
-    using S = XdShape<D>;
+    using S = XdShape<D, L>;
     const int b = blockIdx.y;
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= ((M + 31) & ~31)) return;
     float centre[D];
     launch_centre<D, T>(prm.x, b, N, centre);
     float unused;
-    pack_column_xd<MODE, D, T>(prm, (long)b * M + j, j < M, centre,
-                                                                      pk.rec + b * pk.stride + (long)(j >> 5) * S::kGroupRecs + (j & 31), 32, &unused);
+    pack_column_xd<MODE, D, T, L>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (long)(j >> 5) * S::kGroupRecs + (j & 31), 32,
+                                  &unused);
 }
 
 // LDS-DMA: lane l of the wavefront copies 16 (4) bytes from its own global address to lds_base + 16 l (4 l); lds_base must be
@@ -193,11 +271,17 @@ __device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
 }
 
 // the chained MFMAs of one 32 x 32 block: column group `g` (LDS) against the x-side operands X
-template <int NM, int NBP>
+__device__ __forceinline__ f32x16 mfma_h32(const uint4& a, const uint4& b, const f32x16& c) {
+    Pack16h pa, pb;
+    pa.u = a;
+    pb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(pa.v, pb.v, c, 0, 0, 0);
+}
+template <int NM, int NBP, int L = XL_BF16X3>
 __device__ __forceinline__ f32x16 xd_block(const uint4* __restrict__ g, int rec0, const uint4 (&X)[NM], const f32x16& zero16) {
-    f32x16 u = mfma_x32(g[rec0], X[0], zero16);
+    f32x16 u = (L == XL_F16X2) ? mfma_h32(g[rec0], X[0], zero16) : mfma_x32(g[rec0], X[0], zero16);
 #pragma unroll
-    for (int m = 1; m < NM; ++m) u = mfma_x32(g[m * 64 + rec0], X[m], u);
+    for (int m = 1; m < NM; ++m) u = (L == XL_F16X2) ? mfma_h32(g[m * 64 + rec0], X[m], u) : mfma_x32(g[m * 64 + rec0], X[m], u);
     return u;
 }
 
@@ -215,10 +299,11 @@ __device__ __forceinline__ float xd_weighted_sum(const f32x16& u, const float* _
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE, int L = XL_BF16X3>
 __global__ void __launch_bounds__(NW * 64)
 xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPacked pk) {
-    using S = XdShape<D>;
+    using S = XdShape<D, L>;
+    constexpr float kFloor = (L == XL_F16X2) ? kH2Floor : kMinusHuge;      // the running maximum of a row that has seen no mass yet
     static_assert(!(PRE && SPARSE), "pre-packed columns serve dense launches");
     constexpr int NM = S::NM, NBP = S::NBP, kTileD = PRE ? S::kTilePre : S::kTile;
     constexpr int kRowsPerWave = RT * 32;
@@ -260,19 +345,21 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
             float xi[D];
             load_point<D, T>(prm.x, (long)b * N + i, xi);
             float a[D], n2 = 0.f;
+            const float xscale = (L == XL_F16X2) ? __builtin_sqrtf(prm.s2) : prm.s2;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float xt = xi[d] - centre[d];
                 n2 = __builtin_fmaf(xt, xt, n2);
-                a[d] = xt * prm.s2;
+                a[d] = xt * xscale;
             }
             // scalar item of the x side: [1,1,1,n1,n2,n3]; soft-min: n = -running max (0 until the first group has been seen),
             // gaussian: n = r_i = -s/2 |xt_i|^2, constant
-            const float nrow = (MODE == XD_SOFTMIN) ? 0.f : -0.5f * prm.s2 * n2;
+            float nrow = (MODE == XD_SOFTMIN) ? 0.f : -0.5f * prm.s2 * n2;
+            if (L == XL_F16X2) nrow = __builtin_fmaxf(nrow, kH2Floor);
 #pragma unroll
             for (int mm = 0; mm < NM; ++mm)     // this lane's half of MFMA mm: record 2 mm + half
-                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true>(2 * mm + 1, nrow, a), xd_record_of<D, true>(2 * mm, nrow, a));
-            m[rt] = kMinusHuge;
+                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true, L>(2 * mm + 1, nrow, a), xd_record_of<D, true, L>(2 * mm, nrow, a));
+            m[rt] = kFloor;
             ssum[rt] = 0.f;
         }
         bool first_group = (MODE == XD_SOFTMIN);
@@ -318,12 +405,12 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         for (int k = 0; k < kCols; ++k) {
                             const int t = tid + k * kThreads;
                             if (t < npad)
-                                pack_column_xd<MODE, D, T>(prm, (long)b * M + max(gcols[k], 0), t < n, centre,
+                                pack_column_xd<MODE, D, T, L>(prm, (long)b * M + max(gcols[k], 0), t < n, centre,
                                                            &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32, &tileVBuf[MODE == XD_GAUSS ? t : 0]);
                         }
                     } else {
                         for (int t = tid; t < npad; t += kThreads)
-                            pack_column_xd<MODE, D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32,
+                            pack_column_xd<MODE, D, T, L>(prm, (long)b * M + j0 + t, t < n, centre, &tileBuf[(t >> 5) * (32 * NBP) + (t & 31)], 32,
                                                        &tileVBuf[MODE == XD_GAUSS ? t : 0]);
                     }
                     __syncthreads();
@@ -336,7 +423,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         const uint4* g = &tile[G * (32 * NBP)];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            ssum[rt] += xd_weighted_sum(xd_block<NM, NBP>(g, rec0, X[rt], zero16), &tileV[G * 32 + half * 4]);
+                            ssum[rt] += xd_weighted_sum(xd_block<NM, NBP, L>(g, rec0, X[rt], zero16), &tileV[G * 32 + half * 4]);
                     }
                     return;
                 }
@@ -345,13 +432,13 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                 if (first_group) {   // exact maximum over the first 32 columns
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const f32x16 u = xd_block<NM, NBP>(&tile[0], rec0, X[rt], zero16);
+                        const f32x16 u = xd_block<NM, NBP, L>(&tile[0], rec0, X[rt], zero16);
                         float um = max16(u);
                         um = fmaxf(um, __shfl_xor(um, 32, 64));
-                        um = fmaxf(um, kMinusHuge);
+                        um = fmaxf(um, kFloor);
                         m[rt] = um;
                         ssum[rt] = sum_exp2_16(u, um);
-                        X[rt][0] = select_u4(owns_h, xd_with_n(X[rt][0], -um), X[rt][0]);
+                        X[rt][0] = select_u4(owns_h, xd_with_n<L>(X[rt][0], -um), X[rt][0]);
                     }
                     first_group = false;
                     G0 = 1;
@@ -363,7 +450,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                 for (int G = G0; G < nG; ++G) {
                     const uint4* g = &tile[G * (32 * NBP)];
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(xd_block<NM, NBP>(g, rec0, X[rt], zero16));
+                    for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(xd_block<NM, NBP, L>(g, rec0, X[rt], zero16));
                 }
                 float smax = stmp[0];
 #pragma unroll
@@ -377,8 +464,8 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                             uint4 Xp[NM];
 #pragma unroll
                             for (int mm = 0; mm < NM; ++mm) Xp[mm] = X[rt][mm];
-                            Xp[0] = select_u4(owns_h, xd_with_n(Xp[0], 0.f), Xp[0]);      // n = 0: plain exponents
-                            const f32x16 u = xd_block<NM, NBP>(g, rec0, Xp, zero16);
+                            Xp[0] = select_u4(owns_h, xd_with_n<L>(Xp[0], 0.f), Xp[0]);      // n = 0: plain exponents
+                            const f32x16 u = xd_block<NM, NBP, L>(g, rec0, Xp, zero16);
                             float um = max16(u);
                             um = fmaxf(um, __shfl_xor(um, 32, 64));
                             const float mnew = fmaxf(m[rt], um);
@@ -387,7 +474,7 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
                         }
                     }
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) X[rt][0] = select_u4(owns_h, xd_with_n(X[rt][0], -m[rt]), X[rt][0]);
+                    for (int rt = 0; rt < RT; ++rt) X[rt][0] = select_u4(owns_h, xd_with_n<L>(X[rt][0], -m[rt]), X[rt][0]);
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
@@ -418,7 +505,10 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
         if (wave_active) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // the halves hold the two 16-column halves of every block
+                float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // the halves hold the two 16-column halves of every block
+                // XL_F16X2: a row still at the floor has seen padded / massless columns only, whose exponents were the floor too
+                // (2^0 each): its sum is empty, as in the bf16 layout where such exponents are -1e30 / -inf
+                if (L == XL_F16X2 && MODE == XD_SOFTMIN && m[rt] <= kH2Floor * 0.98f) s = 0.f;
                 const int i = wave_row0 + rt * 32 + l31;
                 if (half == 0 && i < row_end) {
                     const long idx = (long)b * N + i;

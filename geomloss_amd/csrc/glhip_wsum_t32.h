@@ -23,9 +23,9 @@
 
 namespace glhip {
 
-template <int D>
-struct T32Shape {      // the 6-slot K layout of XdShape (glhip_softmin_xd.h) without its D >= 4 restriction
-    static constexpr int NM = (6 * (D + 1) + 15) / 16;
+template <int D, int L = XL_BF16X3>
+struct T32Shape {      // the K layouts of XdShape (glhip_softmin_xd.h): 6 slots per coordinate (bf16 x 3) or 3 (f16 x 2)
+    static constexpr int NM = XdShape<D, L>::NM;
     static constexpr int NBP = 2 * NM;
     // columns per LDS tile: (16 NBP + 4 (D + 1)) bytes each, sized so that LDS never caps the kernel below its 4 waves per SIMD
     // (512 columns left the D = 5 .. 7 kernels two 4-wave workgroups per CU: soft-min gradient at D = 5 230 -> 214 ms)
@@ -38,12 +38,13 @@ struct T32Q {           // components of q_j kept in LDS, accumulators per row
     static constexpr int NA = D + 1;
 };
 
-template <int MODE, int D, typename T, bool SPARSE, int RT, int NW>
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, int L = XL_BF16X3>
 __global__ void __launch_bounds__(NW * 64, 4)      // <= 128 VGPRs: two 8-wave (four 4-wave) workgroups per CU; without the bound the
                                                     // record assembly of the row pass pushes D = 16 to 131 VGPRs = one workgroup per CU (2x slower)
 wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
-    using S = T32Shape<D>;
+    using S = T32Shape<D, L>;
     constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
+    const float xscale = (L == XL_F16X2) ? __builtin_sqrtf(prm.s2) : prm.s2;      // f16 x 2: sqrt(s) on both sides (glhip_softmin_xd.h)
     constexpr int NQ = T32Q<MODE, D>::NQ, NA = T32Q<MODE, D>::NA;
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
@@ -86,15 +87,16 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
             for (int d = 0; d < D; ++d) {
                 const float xt = xi[d] - centre[d];
                 n2 = __builtin_fmaf(xt, xt, n2);
-                a[d] = xt * prm.s2;
+                a[d] = xt * xscale;
             }
             // per-row constant of the exponent: r_i = -s/2 |xt_i|^2, minus (LSE2_i - r_i)'s other half for the soft-min gradient:
             //   C_i = r_i - LSE2_i, LSE2_i = fwd_i / out_scale (+ tscale: value-and-gradient mode, `fwd` is a guess and tscale the margin)
             float cst = -0.5f * prm.s2 * n2;
             if (MODE == WS_SOFTMIN_BWD) cst -= prm.fwd[(long)b * N + i] / prm.out_scale + prm.tscale;
+            if (L == XL_F16X2) cst = __builtin_fminf(__builtin_fmaxf(cst, kH2Floor), -kH2Floor);
 #pragma unroll
-            for (int mm = 0; mm < NM; ++mm)     // scalar item [1,1,1,c1,c2,c3] with c = cst, then six slots per coordinate (xd_record_of)
-                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true>(2 * mm + 1, cst, a), xd_record_of<D, true>(2 * mm, cst, a));
+            for (int mm = 0; mm < NM; ++mm)     // scalar item [1,1,1,c1,c2,c3] with c = cst, then the slots of every coordinate (xd_record_of)
+                X[rt][mm] = select_u4(half != 0, xd_record_of<D, true, L>(2 * mm + 1, cst, a), xd_record_of<D, true, L>(2 * mm, cst, a));
 #pragma unroll
             for (int c = 0; c < NA; ++c) acc[rt][c] = 0.f;
         }
@@ -123,12 +125,17 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                         sj = prm.s[col];
                         H = (MODE == WS_SOFTMIN_BWD) ? __builtin_fmaf(-0.5f * prm.s2, n2, sj * kLog2e) : -0.5f * prm.s2 * n2;
                     }
-                    uint4* base = &tile[(t >> 5) * (32 * NBP) + (t & 31)];
-#pragma unroll
-                    for (int r = 0; r < NBP; ++r) base[r * 32] = xd_record_of<D, false>(r, H, yt);     // record by record: few live pieces
 #pragma unroll
                     for (int d = 0; d < D; ++d) tileQ[d * kTileD + t] = (MODE == WS_SOFTMIN_BWD) ? yt[d] : sj * yt[d];
                     if (MODE != WS_SOFTMIN_BWD) tileQ[D * kTileD + t] = (t < n) ? sj : 0.f;
+                    if (L == XL_F16X2) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) yt[d] *= xscale;
+                        H = __builtin_fmaxf(H, kH2Floor);
+                    }
+                    uint4* base = &tile[(t >> 5) * (32 * NBP) + (t & 31)];
+#pragma unroll
+                    for (int r = 0; r < NBP; ++r) base[r * 32] = xd_record_of<D, false, L>(r, H, yt);     // record by record: few live pieces
                 }
                 __syncthreads();
                 if (!wave_active) continue;
@@ -138,7 +145,7 @@ wsum_t32_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                     f32x16 w[RT];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const f32x16 u = xd_block<NM, NBP>(g, rec0, X[rt], zero16);
+                        const f32x16 u = xd_block<NM, NBP, L>(g, rec0, X[rt], zero16);
 #pragma unroll
                         for (int k = 0; k < 16; ++k) w[rt][k] = fast_exp2(u[k]);
                     }

@@ -22,6 +22,7 @@ GAUSSIAN, LAPLACIAN, ENERGY = 0, 1, 2
 KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
 FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST, FLAG_SMALL_ROW_BLOCKS = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_F16X2 = 256                # exponents from two f16 pieces per coordinate; the caller vouches for the range (glhip.h)
 FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
 XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussian product run on the matrix cores up to this dimension
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 110 /* 0.1.10 */
+#define GLHIP_VERSION 111 /* 0.1.11 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -76,6 +76,14 @@ extern "C" {
 #define GLHIP_FLAG_SMALL_ROW_BLOCKS 128 /* block-sparse soft-min forward / half-step, D <= 3: the pairs sit in row blocks of up to 64 points
                                   (sum of squared block sizes / N <= 64): launch 2-wavefront workgroups over 256-column tiles.  A hint: results
                                   do not depend on it.  The caller knows the block sizes (glhip_block_ranges_kept_pairs returns the sum). */
+
+#define GLHIP_FLAG_F16X2 256 /* p = 2 soft-min (forward, half-step, gradient) and gaussian product / gradient, 4 <= D <= 16 (and the D <= 3
+                                  soft-min forward): form the exponents from TWO f16 pieces per coordinate (3 products, v_mfma_f32_32x32x16_f16)
+                                  instead of three bf16 pieces (6 products) — about half the matrix instructions and LDS bytes.  Cross terms
+                                  good to ~2^-21 relative instead of 2^-24 (csrc/glhip_softmin_xd.h).  THE CALLER VOUCHES FOR THE RANGE: every
+                                  exponent term (log2(e) h_j, |x - y|^2 / (2 eps ln 2)) must stay below ~2.6e5 in magnitude, i.e. roughly
+                                  (cloud diameter)^2 / eps < 3e5; beyond that f16 overflows and the results are inf / nan.  Ignored by kernels
+                                  without that layout (p = 1, laplacian, energy, D > 16, float64). */
 
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
