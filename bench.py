@@ -56,7 +56,12 @@ VALU_PEAK_PAIRS_PER_S = SIMDS * CLOCK_HZ * 64 / NOMINAL_CYCLES_PER_64_PAIRS
 # measured on this part (tools/ubench, profiles/r01_ubench_pipes.txt): that exp2 + add stream alone runs at 12.5
 # cycles per 64 pairs (v_exp_f32 8.2-9.7, v_add_f32 2.5-3.1), the kernel's bare inner loop (MFMA pair + stream) at 13.5
 MEASURED_STREAM_CYCLES = 12.5
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_softmin.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_pmc_softmin.json")
+# The launch the headline times: what SamplesLoss("sinkhorn", blur=.05) runs on unit-cube clouds — exponents from two f16 pieces per
+# coordinate, ONE v_mfma_f32_32x32x16_f16 per 1024 pairs (GLHIP_FLAG_F16X2; in range here: diameter^2 / eps = 1200, the flag's
+# contract allows ~1.5e5).  The default layout of a raw C-ABI call (bf16 x 3, two MFMAs) is timed next to it (`bf16x3_layout`).
+HEADLINE_FLAGS = 256
+DOMINANT_KERNELS = ("xd_fwd_kernel", "softmin_fwd_x32_kernel")
 
 
 def log(*a):
@@ -135,7 +140,7 @@ def measure_traffic(points, timeout_s=120):
     """HBM traffic of the dominant kernel, measured HERE: two `rocprofv3 --pmc <counter> --kernel-trace` passes (FETCH_SIZE and
     WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over a minimal run of this very command
     (`bench.py --no-extras`: warm-up + 2 timed launches).  Counters are KiB per dispatch, averaged over the launches of
-    softmin_fwd_x32_kernel; FETCH_SIZE is doubled (gfx950 counts the 128-byte requests of a wide coalesced read at 64 bytes: the
+    the dominant kernel (xd_fwd_kernel<.., D = 3, f16 x 2>); FETCH_SIZE is doubled (gfx950 counts the 128-byte requests of a wide coalesced read at 64 bytes: the
     guide's correction — our column loads are such reads, the doubled figure is the upper estimate).  Returns a dict or None."""
     import glob
     import shutil
@@ -161,14 +166,14 @@ def measure_traffic(points, timeout_s=120):
                 rows = con.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
                                    "group by kernel_name, counter_name").fetchall()
                 for k, cn, n, avg, dur in rows:
-                    if "softmin_fwd_x32_kernel" in k and cn == counter:
+                    if any(name in k for name in DOMINANT_KERNELS) and cn == counter:
                         got[counter] = {"kib_per_launch": avg, "launches": n, "kernel_ns_under_profiler": dur}
         if "FETCH_SIZE" not in got or "WRITE_SIZE" not in got:
             return None
         f, w = got["FETCH_SIZE"]["kib_per_launch"], got["WRITE_SIZE"]["kib_per_launch"]
         return {"bytes_per_launch": (2.0 * f + w) * 1024.0, "bytes_per_launch_uncorrected": (f + w) * 1024.0, "counters": got,
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, two passes over `bench.py --no-extras`, run by this "
-                          "process; softmin_fwd_x32_kernel only (the pack and merge kernels of the same call move 64 + 125 MB more)"}
+                          "process; the reducing kernel only (the pack and merge kernels of the same call move ~0.2 GB more)"}
     except Exception as e:      # a profiler hiccup must not cost the bench line
         log(f"[bench] traffic leg failed: {e!r}")
         return None
@@ -207,12 +212,16 @@ def hot_path_kernels(dev, n=1_000_000):
     add("laplacian_product", fresh(lambda: hip.kernel_conv("laplacian", x2, y2, v1, blur)), reps=2)
     add("energy_product", fresh(lambda: hip.kernel_conv("energy", x2, y2, v1, blur)), reps=2)
     add("softmin_fwd_p1_direct_differences", lambda: hip.softmin_fwd_raw(x, y, h, 0.05, 1), reps=1)
-    # 4 <= D <= 16: the same bf16x3 exponent as a chain of ceil(6 (D + 1) / 16) MFMAs (csrc/glhip_softmin_xd.h)
+    # 4 <= D <= 16 (csrc/glhip_softmin_xd.h): f16 x 2 exponents, ceil((3 D + 6) / 16) chained MFMAs (GLHIP_FLAG_F16X2, in range on the
+    # unit cube), and the default bf16 x 3 layout, ceil(6 (D + 1) / 16)
     gd = torch.Generator().manual_seed(11)
     for D in (4, 5, 8, 12, 16):
         xd = torch.rand(1, n, D, generator=gd).to(dev)
         yd = torch.rand(1, n, D, generator=gd).to(dev)
-        add(f"softmin_fwd_p2_d{D}", lambda: hip.softmin_fwd_raw(xd, yd, h, eps, 2), reps=2)
+        add(f"softmin_fwd_p2_d{D}", lambda: hip.softmin_fwd_raw(xd, yd, h, eps, 2, flags=HEADLINE_FLAGS), reps=2)
+        if D in (8, 16):
+            add(f"softmin_fwd_p2_d{D}_bf16x3", lambda: hip.softmin_fwd_raw(xd, yd, h, eps, 2), reps=1)
+            add(f"softmin_bwd_x_p2_d{D}", lambda: hip.softmin_bwd_x_raw(xd, yd, h, out, g, eps, 2, flags=HEADLINE_FLAGS), reps=1)
         if D == 4:
             add("gaussian_product_d4", lambda: hip.kernel_conv_fwd_raw(hip.GAUSSIAN, xd, yd, v, 2 * blur), reps=2)
     # float64 clouds (csrc/glhip_api_f64.hip): one thread per row, no matrix cores — timed on a tenth of the rows
@@ -374,7 +383,7 @@ def run_headline(args, dev):
     n = args.points
     x, y, h, eps = make_problem(n, dev, seed=1000)
     for _ in range(args.warmup):
-        hip.softmin_fwd_raw(x, y, h, eps, 2)
+        hip.softmin_fwd_raw(x, y, h, eps, 2, flags=HEADLINE_FLAGS)
     settle_host()
     torch.cuda.synchronize()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -382,7 +391,7 @@ def run_headline(args, dev):
     t0 = time.perf_counter()
     for k in range(args.steps):
         starts[k].record()               # same stream as the launch (torch's current stream)
-        hip.softmin_fwd_raw(x, y, h, eps, 2)
+        hip.softmin_fwd_raw(x, y, h, eps, 2, flags=HEADLINE_FLAGS)
         stops[k].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -416,10 +425,10 @@ def run_headline(args, dev):
         "roofline": {
             "bound": "valu", "achieved": kernel_pairs_s / 1e12, "peak": VALU_PEAK_PAIRS_PER_S / 1e12, "unit": "Tpair/s",
             "frac": kernel_pairs_s / VALU_PEAK_PAIRS_PER_S, "traffic": None,
-            "model": "VALU issue: 1 v_exp_f32 (quarter rate, 8 cycles per wave64) + 1 v_add_f32 (2 cycles) per pair, the bf16x3 "
-                     "MFMA that forms the exponent co-issues -> 10 SIMD cycles per 64 pairs; 256 CU x 4 SIMD x 2.4 GHz",
-            "kernel": "softmin_fwd_x32_kernel (+ pack_columns_kernel + merge_kernel: one glhip_softmin_fwd call; the x32 kernel is "
-                      "> 99.9 % of it)",
+            "model": "VALU issue: 1 v_exp_f32 (quarter rate, 8 cycles per wave64) + 1 v_add_f32 (2 cycles) per pair, the one f16 x 2 "
+                     "MFMA per 1024 pairs that forms the exponents co-issues -> 10 SIMD cycles per 64 pairs; 256 CU x 4 SIMD x 2.4 GHz",
+            "kernel": "xd_fwd_kernel<XD_SOFTMIN, D = 3, f16 x 2> (+ xd_pack_kernel + merge_kernel: one glhip_softmin_fwd call with "
+                      "GLHIP_FLAG_F16X2; the reducing kernel is > 99.9 % of it)",
             "kernel_ms": kernel_ms, "kernel_pairs_per_s": kernel_pairs_s,
             "frac_of_measured_stream": kernel_pairs_s / (SIMDS * CLOCK_HZ * 64 / MEASURED_STREAM_CYCLES),
             "measured_stream": f"{MEASURED_STREAM_CYCLES} cycles per 64 pairs: the same exp2 + add instruction stream micro-benchmarked "
@@ -434,6 +443,11 @@ def run_headline(args, dev):
         },
     }
     if not args.no_extras:
+        ms3 = event_ms(lambda: hip.softmin_fwd_raw(x, y, h, eps, 2), 3)
+        res["roofline"]["bf16x3_layout"] = {"kernel_ms": ms3, "kernel_pairs_per_s": pairs_per_launch / (ms3 * 1e-3),
+                                            "note": "the same launch without GLHIP_FLAG_F16X2: softmin_fwd_x32_kernel, three bf16 pieces per "
+                                                    "operand, two MFMAs per 1024 pairs — what a raw C-ABI call gets when it does not vouch for the range"}
+        log(f"[bench] same launch, bf16 x 3 layout: {ms3:.2f} ms")
         if not args.no_traffic:
             t = measure_traffic(n)
             if t is not None:

@@ -733,6 +733,19 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
                 return GLHIP_OK;
             }
         }
+        if constexpr (!BWD) {
+            // GLHIP_FLAG_F16X2, D <= 3: 3 D + 6 <= 15 K slots = ONE v_mfma_f32_32x32x16_f16 per 1024 exponents (bf16 x 3: two), 32 bytes
+            // of LDS per column (64) — the kernel of glhip_softmin_xd.h instantiated for D <= 3
+            // Big dense launches only (pre-packed columns, XCD-aware grid): that is where it was measured to win — 87.1 -> 79.2 ms at
+            // 1e6 x 1e6, 36.8 -> 35.0 ms per online loss at 1e5; batches of 4096 x 4096 problems lose 4 % to the x32 kernel's staging
+            // (B = 256: 16.2 -> 17.0 ms per loss), and block-sparse launches keep the gathered pre-packed tiles of glhip_softmin_x32.h.
+            if (p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {
+                if (D == 1) launch_xd_l<XD_SOFTMIN, 1, T, SoftminFwdOp<1, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
+                else if (D == 2) launch_xd_l<XD_SOFTMIN, 2, T, SoftminFwdOp<2, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
+                else launch_xd_l<XD_SOFTMIN, 3, T, SoftminFwdOp<3, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
+                return GLHIP_OK;
+            }
+        }
         if (D == 1) launch_softmin_d<1, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else if (D == 2) launch_softmin_d<2, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);

@@ -104,10 +104,10 @@ def _fp32_weights(a, b):
     return a, b
 
 
-def softmin_online(eps, C_xy, h_y, p=2, plan=None):
+def softmin_online(eps, C_xy, h_y, p=2, plan=None, flags=0):
     """Soft-C-transform on implicit costs (``:337-346`` and ``:229-290``): C_xy = (x, y), batched or not."""
     x, y = C_xy
-    out = hip.softmin(eps, x, y, h_y, p=p, plan=plan)
+    out = hip.softmin(eps, x, y, h_y, p=p, plan=plan, flags=flags)
     return out if x.dim() > 2 else out.view(1, -1)
 
 
@@ -117,6 +117,7 @@ class _HipSoftmin:
 
     def __init__(self, p, multiscale):
         self.p, self.multiscale = p, multiscale
+        self.h2_min_eps = float("inf")      # see set_range: temperatures from which the f16 x 2 exponent layout is in range
         self._plan = None   # (x, y, a_log, b_log, debias, hip.Iter4Plan) of the loop being run
         self._dist_plans = {}   # p = 1, dense: (id(x), id(y)) -> (x, y, hip.compact_rows_plan): voxel-sorted copies, per loop
 
@@ -132,10 +133,22 @@ class _HipSoftmin:
             hit = self._dist_plans[key] = (x, y, hip.compact_rows_plan(x, y))
         return hit[2]
 
+    def set_range(self, diameter, measured):
+        """Tells the soft-min how wide the clouds are, so that it can ask for the f16 x 2 exponent layout (GLHIP_FLAG_F16X2: about half
+        the matrix instructions and LDS bytes of the default bf16 x 3 one) where the exponents fit f16's range: terms of size
+        log2(e) diameter^2 / eps must stay below ~2.6e5.  With a diameter measured on the data that is eps >= 2e-5 diameter^2 (a
+        factor 3 of headroom); a diameter GIVEN by the caller only parametrises the schedule and may understate the clouds, so it
+        gets a factor 15 (eps >= 1e-4 diameter^2: blur / diameter >= 0.01).  p = 2 only; GEOMLOSS_HIP_F16X2=0 keeps bf16 x 3."""
+        if self.p == 2 and _F16X2 and diameter is not None and diameter > 0:
+            self.h2_min_eps = (2e-5 if measured else 1e-4) * float(diameter) ** 2
+
+    def _flags(self, eps):
+        return hip.FLAG_F16X2 if eps >= self.h2_min_eps else 0
+
     def __call__(self, eps, C, h):
         if self.multiscale:
-            return softmin_multiscale(eps, C, h, p=self.p)
-        return softmin_online(eps, C, h, p=self.p, plan=self._dist_plan(C[0], C[1]))
+            return softmin_multiscale(eps, C, h, p=self.p, flags=self._flags(eps))
+        return softmin_online(eps, C, h, p=self.p, plan=self._dist_plan(C[0], C[1]), flags=self._flags(eps))
 
     def step(self, eps, C, log_w, pot, damping, prev):
         x, y = C[0], C[1]
@@ -145,7 +158,7 @@ class _HipSoftmin:
             return ft if prev is None else 0.5 * (prev + ft)
         flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
         out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges,
-                                plan=self._dist_plan(x, y))
+                                plan=self._dist_plan(x, y), flags=self._flags(eps))
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
     def value_and_grad(self, eps, C, log_w, pot_new, pot_old, f_new, f_old, damping):
@@ -159,7 +172,7 @@ class _HipSoftmin:
         flat = (lambda t: t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
         guess = (2.0 * f_new - f_old) / damping
         margin = (pot_new - pot_old).abs().max()
-        out = hip.softmin_value_and_grad(eps, x, y, flat(log_w + pot_new / eps), flat(guess), margin, ranges=ranges)
+        out = hip.softmin_value_and_grad(eps, x, y, flat(log_w + pot_new / eps), flat(guess), margin, ranges=ranges, flags=self._flags(eps))
         if out is None:
             return None
         out = damping * out
@@ -204,6 +217,7 @@ class _HipSoftmin:
 # Opt-in (GEOMLOSS_HIP_GRAPH=1 or set_graph_mode(True)) and only when `diameter` is given, because the temperatures are
 # kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
+_F16X2 = os.environ.get("GEOMLOSS_HIP_F16X2", "1") != "0"      # f16 x 2 exponents where the temperature allows (_HipSoftmin.set_range)
 _fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
 # ... up to this many pairs per soft-min; bigger problems fill the GPU with one soft-min per launch (pre-packed columns, XCD grids)
 _ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "4e9"))   # measured: B x 4096^2 with B = 32..128 and N = 3e4 gain 5-13 %, 7e4+ lose
@@ -245,6 +259,7 @@ def sinkhorn_online(
     C_xy, C_yx = ((x, y.detach()), (y, x.detach()))
 
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+    softmin.set_range(diameter, measured=not diameter_given)
 
     a_log, b_log = log_weights(a), log_weights(b)
     # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
@@ -270,6 +285,7 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
         # replay and every buffer lives in the graph's private pool (a plan left over from the warm-up pass would freeze the
         # first call's converted clouds into the graph and leave the replays writing into freed memory).
         sm = _HipSoftmin(softmin.p, multiscale=False)
+        sm.h2_min_eps = softmin.h2_min_eps
         Cxx, Cyy = ((xs, xs), (ys, ys)) if debias else (None, None)
         out = sinkhorn_loop(sm, al, bl, Cxx, Cyy, (xs, ys), (ys, xs), eps_list, rho, debias=debias,
                             last_extrapolation=False)
@@ -302,10 +318,10 @@ def _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias):
 # ==============================================================================
 
 
-def softmin_multiscale(eps, C_xy, f_y, p=2):
+def softmin_multiscale(eps, C_xy, f_y, p=2, flags=0):
     """Block-sparse soft-C-transform (``:445-450``): C_xy = (x, y, ranges_x, ranges_y, ranges_xy)."""
     x, y, ranges_x, ranges_y, ranges_xy = C_xy
-    return hip.softmin(eps, x, y, f_y.view(-1), p=p, ranges=ranges_xy)
+    return hip.softmin(eps, x, y, f_y.view(-1), p=p, ranges=ranges_xy, flags=flags)
 
 
 def clusterize(a, x, scale=None, labels=None):
@@ -446,7 +462,9 @@ def sinkhorn_multiscale(
     softmin = _HipSoftmin(p_kernel, multiscale=True)
     extrapolate = partial(extrapolate_samples, softmin=softmin)
 
+    diameter_given = diameter is not None
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
+    softmin.set_range(diameter, measured=not diameter_given)
 
     # voxel size: about 2000 cells over the bounding box
     if cluster_scale is None:

@@ -250,22 +250,27 @@ def test_gradient_kernels_1e6_sampled_rows(cuda):
 
 
 def test_headline_launch_all_rows(cuda):
-    """The EXACT launch bench.py times (``bench.make_problem(1e6, seed=1000)`` -> ``hip.softmin_fwd_raw``: pre-packed columns, 32
-    XCD-aware column splits, merge), every one of its 1e6 rows against the brute-force float64 HIP oracle (1e12 float64 pair
+    """The EXACT launch bench.py times (``bench.make_problem(1e6, seed=1000)`` -> ``hip.softmin_fwd_raw(flags=HEADLINE_FLAGS)``:
+    pre-packed columns, XCD-aware column splits, merge), every one of its 1e6 rows against the brute-force float64 HIP oracle (1e12 float64 pair
     evaluations, ~4 s).  Bar: 1.5e-6 absolute on values of size 0.1 ... 1.5 (fp32 resolution of the expanded exponent, as in
     tests/test_hip_kernels.py); measured margin in the line printed."""
     import bench
     from oracle import oracle_hip64
     n = 1_000_000
     x, y, h, eps = bench.make_problem(n, cuda, seed=1000)
-    out = hip.softmin_fwd_raw(x, y, h, eps, 2)
+    out = hip.softmin_fwd_raw(x, y, h, eps, 2, flags=bench.HEADLINE_FLAGS)      # f16 x 2 exponents: the launch of the bench line
+    assert bench.HEADLINE_FLAGS == hip.FLAG_F16X2
     assert out.shape == (1, n) and bool(torch.isfinite(out).all())
+    out3 = hip.softmin_fwd_raw(x, y, h, eps, 2)                                  # ... and the default bf16 x 3 layout of a raw call
     ref = oracle_hip64.softmin(eps, x[0], y[0], h[0], 2, device=cuda)
     err = (out[0].double() - ref).abs()
     worst = int(err.argmax())
     print(f"headline launch, all {n} rows: max abs error {err.max().item():.3e} (row {worst}, value {ref[worst].item():.6f}), "
           f"mean abs error {err.mean().item():.3e}, value range [{ref.min().item():.4f}, {ref.max().item():.4f}]")
     assert err.max().item() < 1.5e-6
+    err3 = (out3[0].double() - ref).abs()
+    print(f"   bf16 x 3 layout: max abs error {err3.max().item():.3e}, mean {err3.mean().item():.3e}")
+    assert err3.max().item() < 1.5e-6
 
 
 def test_cfg4_whole_batch_256_through_the_sharded_loss(cuda):
