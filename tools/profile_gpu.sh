@@ -15,6 +15,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o pmc -- $CMD > $OUT/pmc_tcc.log 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 --kernel-trace -d $OUT/pmc_pipe -o pmc -- $CMD > $OUT/pmc_pipe.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace -d $OUT/pmc_f16 -o pmc -- $CMD > $OUT/pmc_f16.log 2>&1
 timeout 300 rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace -d $OUT/pmc_util -o pmc -- $CMD > $OUT/pmc_util.log 2>&1
 cd $REPO
 find $OUT -name "*.csv" | head -50

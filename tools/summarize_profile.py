@@ -31,7 +31,7 @@ def main():
     print(open(os.path.join(out_dir, f"{tag}_kernel_trace_stats.txt")).read())
 
     counters = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc", "pmc_pipe", "pmc_util"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc", "pmc_pipe", "pmc_f16", "pmc_util"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
@@ -65,7 +65,7 @@ def main():
             # cycles / 8 / kernel time = effective clock under this load
             summary["effective_clock_GHz"] = g["avg_per_launch"] / 8.0 / g["avg_kernel_ns"]
         for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_MFMA_BF16",
-                     "VALUBusy", "MfmaUtil"):
+                     "SQ_INSTS_VALU_MFMA_F16", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "VALUBusy", "MfmaUtil"):
             if name in c:
                 summary[name + "_per_launch"] = c[name]["avg_per_launch"]
     path = os.path.join(out_dir, f"{tag}_pmc_softmin.json")
