@@ -484,7 +484,8 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
 }
 
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
-template <int MODE, int D, typename T, class MergeOp, int RT, int L>
+// WQ: the weighted sums on the matrix cores too (wsum_t32q_kernel: soft-min gradient, f16 x 2, one row tile per wavefront)
+template <int MODE, int D, typename T, class MergeOp, int RT, int L, bool WQ = false>
 void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params& mprm, const Ranges& rg, int n_ranges, int B, int N,
                      int M, const Scratch& sc, hipStream_t st) {
     constexpr int kPart = (MODE == WS_GAUSS_BWD) ? D : D + 1;
@@ -510,17 +511,20 @@ void launch_wsum_t32_rt(const WsumParams<T>& prm, const typename MergeOp::Params
             sp.n_splits = nx;
             sp.xcd_grid_x = gx;
             sp.xcd_blocks = gx * B;
-            hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            if constexpr (WQ) hipLaunchKernelGGL((wsum_t32q_kernel<D, T, false, NW>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+            else hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
             return;
         }
     }
     if (n_ranges > 0) {
-        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, true, RT, NW, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        if constexpr (WQ) hipLaunchKernelGGL((wsum_t32q_kernel<D, T, true, NW>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
+        else hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, true, RT, NW, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     } else {
-        hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        if constexpr (WQ) hipLaunchKernelGGL((wsum_t32q_kernel<D, T, false, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+        else hipLaunchKernelGGL((wsum_t32_kernel<MODE, D, T, false, RT, NW, L>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp);
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3(gx, B, 1), dim3(kBlock), 0, st, mprm, rg, N, sp);
     }
@@ -531,6 +535,13 @@ void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& m
                      int M, const Scratch& sc, hipStream_t st) {
     // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8 — measured 3-16 % faster
     // than 1 tile there (profiles/r03_grad_kernels_ab.txt); beyond, the x-side operands of two tiles no longer fit 128 VGPRs
+    if constexpr (MODE == WS_SOFTMIN_BWD) {
+        static const int wq_min_d = getenv("GLHIP_WQ_MIN_D") ? atoi(getenv("GLHIP_WQ_MIN_D")) : 7;      // tuning knob (17: never)
+        if (sc.h2 && D >= wq_min_d) {
+            launch_wsum_t32_rt<MODE, D, T, MergeOp, 1, XL_F16X2, true>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
+            return;
+        }
+    }
     if (sc.h2) launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), XL_F16X2>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
     else launch_wsum_t32_rt<MODE, D, T, MergeOp, (D <= 8 ? 2 : 1), XL_BF16X3>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
