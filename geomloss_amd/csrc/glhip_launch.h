@@ -20,6 +20,7 @@
 #include "glhip_dist_grad_x32.h"
 #include "glhip_softmin_xd.h"
 #include "glhip_wsum_t32.h"
+#include "glhip_dist_xd.h"
 
 using namespace glhip;
 
@@ -483,6 +484,27 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
     else launch_xd_l<MODE, D, T, MergeOp, XL_BF16X3>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
 }
 
+// distance reductions for 4 <= D <= 16, dense launches (glhip_dist_xd.h): soft-min p = 1 / fused half-step, laplacian and energy products
+template <int MODE, int D, typename T, class MergeOp>
+void launch_dist_xd(const DistParams<T>& prm, const typename MergeOp::Params& mprm, int B, int N, int M, const Scratch& sc, hipStream_t st) {
+    constexpr int NW = 8, kRows = NW * 32;
+    constexpr int kPart = MODE == DM_SOFTMIN_P1 ? 2 : 1;
+    static_assert(MergeOp::kPartial == kPart && MergeOp::kRows == 1, "partial formats differ");
+    const int gx = (N + kRows - 1) / kRows;
+    const long per_split = (long)B * N * kPart * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits((long)gx * B, M, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * kPart;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    const Ranges none{nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((dist_xd_kernel<MODE, D, T, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, N, M, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, mprm, none, N, sp);
+}
+
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
 // WQ: the weighted sums on the matrix cores too (wsum_t32q_kernel: soft-min gradient, f16 x 2, one row tile per wavefront)
 template <int MODE, int D, typename T, class MergeOp, int RT, int L, bool WQ = false>
@@ -762,6 +784,15 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
         else launch_softmin_d<3, BWD, T>(prm, rg, n_ranges, B, N, M, p, direct, mfma, xdl, sc, st);
     } else {
         if constexpr (!BWD) {
+            if (p == 1 && D <= kXdMaxD && n_ranges == 0 && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // distances on the matrix cores
+                const SoftminParams<T> mprm = make_softmin_params<T>(x, y, h, out, eps, 1, step.pot, step.prev, step.alpha, step.beta);
+                const DistParams<T> dp{mprm.x, mprm.y, h, step.pot, step.prev, out, s2, 1e-8f * s2 * s2, out_scale, 1.0f / eps, step.alpha, step.beta,
+                                       dist_guard()};
+#define GL_XD(DD) launch_dist_xd<DM_SOFTMIN_P1, DD, T, SoftminFwdOp<DD, 1, true, 1, T>>(dp, mprm, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
             if (p == 2 && D <= kXdMaxD && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // 4 <= D <= 16: matrix cores
                 SoftminParams<T> prm = make_softmin_params<T>(x, y, h, out, eps, 2, step.pot, step.prev, step.alpha, step.beta);
 #define GL_XD(DD) launch_xd<XD_SOFTMIN, DD, T, SoftminFwdOp<DD, 2, false, 1, T>>(prm, prm, rg, n_ranges, B, N, M, sc, st)
@@ -926,6 +957,20 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
         }
     } else {
         if constexpr (!BWD) {
+            if (kind != GLHIP_GAUSSIAN && D <= kXdMaxD && n_ranges == 0 && !(flags & GLHIP_FLAG_NO_MFMA)) {   // laplacian / energy: distances on the matrix cores
+                const bool lap = kind == GLHIP_LAPLACIAN;
+                const float t = lap ? kLog2e / blur : 1.0f;
+                ConvParams<T> mprm;
+                mprm.x = static_cast<const T*>(x); mprm.y = static_cast<const T*>(y); mprm.v = v; mprm.out = out; mprm.g = nullptr; mprm.gx = nullptr;
+                mprm.t = t; mprm.gscale = 0.f; mprm.clamp2 = 1e-8f * (lap ? kLog2e * kLog2e : 1.f);
+                const DistParams<T> dp{mprm.x, mprm.y, v, nullptr, nullptr, out, t, mprm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
+#define GL_XD(DD) \
+    if (lap) launch_dist_xd<DM_LAPLACIAN, DD, T, ConvOp<GLHIP_LAPLACIAN, DD, 1, T, 0>>(dp, mprm, B, N, M, sc, st); \
+    else launch_dist_xd<DM_ENERGY, DD, T, ConvOp<GLHIP_ENERGY, DD, 1, T, 0>>(dp, mprm, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
             if (kind == GLHIP_GAUSSIAN && D <= kXdMaxD && !(flags & GLHIP_FLAG_NO_MFMA)) {   // 4 <= D <= 16: matrix cores
                 // the gaussian exponent -|x-y|^2 / (2 blur^2) is the soft-min's with eps = blur^2 and h = 0; `h` carries v
                 const SoftminParams<T> prm = make_softmin_params<T>(x, y, v, out, blur * blur, 2, nullptr, nullptr, 1.f, 0.f);

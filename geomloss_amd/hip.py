@@ -834,23 +834,26 @@ def softmin(eps, x, y, h, p=2, ranges=None, flags=0, plan=None):
     return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS, plan)
 
 
-def fused_step_applies(D, p=2, flags=0):
+def fused_step_applies(D, p=2, flags=0, sparse=False):
     """Whether ``glhip_sinkhorn_step`` has a kernel for clouds of dimension D: every operator for D <= 3; for 4 <= D <= XD_MAX_DIM
-    only the p = 2 matrix-core kernel (glhip_softmin_xd.h), which GLHIP_FLAG_NO_MFMA / GLHIP_FLAG_DIRECT switch off — the
-    generic-dimension kernel those flags fall back to has no fused half-step."""
+    the matrix-core kernels — p = 2 (glhip_softmin_xd.h), and since round 5 p = 1 on DENSE launches (glhip_dist_xd.h; ``sparse``:
+    the launch carries block-sparse ranges) — which GLHIP_FLAG_NO_MFMA / GLHIP_FLAG_DIRECT switch off: the generic-dimension
+    kernel those flags fall back to has no fused half-step."""
     if D <= 3:
         return True
-    return p == 2 and D <= XD_MAX_DIM and not ((int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT))
+    if D > XD_MAX_DIM or ((int(flags) | ENV_FLAGS) & (FLAG_NO_MFMA | FLAG_DIRECT)):
+        return False
+    return p == 2 or (p == 1 and not sparse)
 
 
 def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0, plan=None):
     """One non-differentiable half-step of the Sinkhorn loop on the GPU: (prev + damping * softmin(eps, C, logw + pot/eps)) / 2,
     or damping * softmin(...) when prev is None — ONE launch where :func:`fused_step_applies`, the soft-min kernel followed by
-    torch arithmetic elsewhere (D > 16, p = 1 in D > 3, D > 3 under GLHIP_FLAG_NO_MFMA / GLHIP_FLAG_DIRECT).
+    torch arithmetic elsewhere (D > 16, block-sparse p = 1 in D > 3, D > 3 under GLHIP_FLAG_NO_MFMA / GLHIP_FLAG_DIRECT).
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); logw, pot: (M,)|(B,M) (pot may be None); prev: (N,)|(B,N) or None.
     Returns fp32 (N,)|(B,N).  Used by the drivers inside the no-grad part of ``sinkhorn_loop``."""
-    if not fused_step_applies(x.shape[-1], p, flags) or is_f64(x):      # (float64 clouds: the double-precision kernels have no fused form)
+    if not fused_step_applies(x.shape[-1], p, flags, ranges is not None) or is_f64(x):      # (float64 clouds: the double-precision kernels have no fused form)
         with torch.no_grad():
             h = _vec(logw, x) if pot is None else _vec(logw, x) + _vec(pot, x).reshape(logw.shape) / eps
             ft = damping * softmin(eps, x.detach(), y.detach(), h, p=p, ranges=ranges, flags=flags, plan=plan)

@@ -153,7 +153,7 @@ class _HipSoftmin:
     def step(self, eps, C, log_w, pot, damping, prev):
         x, y = C[0], C[1]
         ranges = C[4] if self.multiscale else None
-        if not hip.fused_step_applies(x.shape[-1], self.p):  # no fused kernel on the generic-dimension path (incl. D > 3 under NO_MFMA / DIRECT)
+        if not hip.fused_step_applies(x.shape[-1], self.p, 0, ranges is not None):  # no fused kernel on the generic-dimension path (incl. D > 3 under NO_MFMA / DIRECT)
             ft = damping * self(eps, C, log_w if pot is None else log_w + pot / eps)
             return ft if prev is None else 0.5 * (prev + ft)
         flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)

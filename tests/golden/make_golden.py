@@ -74,6 +74,11 @@ CASES = {
     "laplacian_batch": (dict(loss="laplacian", blur=0.2), 23, 2, 110, 100, 3, True),
     "sinkhorn_p1_reach_d2": (dict(loss="sinkhorn", p=1, blur=0.05, reach=0.5), 24, 0, 170, 190, 2, True),
     "sinkhorn_p1_batch": (dict(loss="sinkhorn", p=1, blur=0.05, diameter=1.8), 25, 2, 100, 120, 3, True),
+    # round 5: the distance reductions (p = 1, laplacian, energy) for 4 <= D <= 16 on the matrix cores (csrc/glhip_dist_xd.h)
+    "sinkhorn_p1_d5": (dict(loss="sinkhorn", p=1, blur=0.1), 26, 0, 130, 150, 5, True),
+    "laplacian_d8": (dict(loss="laplacian", blur=0.3), 27, 0, 140, 120, 8, True),
+    "energy_d6": (dict(loss="energy"), 28, 0, 150, 130, 6, True),
+    "sinkhorn_p1_d12_batch": (dict(loss="sinkhorn", p=1, blur=0.2, diameter=3.0), 29, 2, 90, 100, 12, True),
     # mid-size cases: what pins the chunked full-size oracle (oracle/oracle_torch64.py) beyond the sizes NumPy handles
     "sinkhorn_p2_n8000": (dict(loss="sinkhorn", p=2, blur=0.05), 16, 0, 8000, 7000, 3, True),
     "gaussian_n8000": (dict(loss="gaussian", blur=0.05), 17, 0, 8000, 7000, 3, True),

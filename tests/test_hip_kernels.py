@@ -481,10 +481,15 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
     ref = damping * (oracle_c.softmin(eps, x, y, logw, p) if B is None else
                      np.stack([oracle_c.softmin(eps, x[b], y[b], logw[b], p) for b in range(B)]))
     assert np.abs(first.cpu().numpy() - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max()
-    # no fused kernel beyond D = 3 for p = 1 (p = 2: up to D = 16, tests/test_xd_kernels_gpu.py): composed from the soft-min kernel
+    # p = 1 beyond D = 3: fused on dense launches since round 5 (glhip_dist_xd.h), composed from the soft-min kernel on block-sparse ones
     x5, y5, z5 = torch.rand(10, 5, device=cuda), torch.rand(12, 5, device=cuda), torch.zeros(12, device=cuda)
-    assert not hip.fused_step_applies(5, 1)
+    assert hip.fused_step_applies(5, 1) and not hip.fused_step_applies(5, 1, 0, True) and not hip.fused_step_applies(5, 1, hip.FLAG_NO_MFMA)
+    prev5 = torch.rand(10, device=cuda)
     assert torch.allclose(hip.sinkhorn_step(eps, x5, y5, z5, None, None, 0.5, p=1), 0.5 * hip.softmin(eps, x5, y5, z5, p=1), rtol=0, atol=1e-6)
+    assert torch.allclose(hip.sinkhorn_step(eps, x5, y5, z5, 0.3 * z5 + 0.01, prev5, 0.5, p=1),
+                          0.5 * (prev5 + 0.5 * hip.softmin(eps, x5, y5, z5 + (0.3 * z5 + 0.01) / eps, p=1)), rtol=0, atol=1e-6)
+    assert torch.allclose(hip.sinkhorn_step(eps, x5, y5, z5, None, None, 0.5, p=1, flags=hip.FLAG_NO_MFMA), 0.5 * hip.softmin(eps, x5, y5, z5, p=1),
+                          rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (130, 2100, 2, None), (257, 255, 1, 3), (3000, 40, 3, None)])

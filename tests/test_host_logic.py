@@ -377,7 +377,9 @@ def test_fused_half_step_dispatch_follows_the_flags(monkeypatch):
         monkeypatch.setattr(hip, "ENV_FLAGS", env)
         assert all(hip.fused_step_applies(D, p) for D in (1, 2, 3) for p in (1, 2))
         assert all(hip.fused_step_applies(D, 2) for D in (4, 5, 8, 16)) and not hip.fused_step_applies(17, 2)
-        assert not any(hip.fused_step_applies(D, 1) for D in (4, 8, 16, 17))
+        assert all(hip.fused_step_applies(D, 1) for D in (4, 8, 16)) and not hip.fused_step_applies(17, 1)      # dense p = 1: glhip_dist_xd.h
+        assert not any(hip.fused_step_applies(D, 1, 0, True) for D in (4, 8, 16, 17))                            # block-sparse p = 1: composed
+        assert all(hip.fused_step_applies(D, 2, 0, True) for D in (4, 8, 16))
     for env in (hip.FLAG_NO_MFMA, hip.FLAG_DIRECT, hip.FLAG_NO_MFMA | hip.FLAG_DIRECT):
         monkeypatch.setattr(hip, "ENV_FLAGS", env)
         assert all(hip.fused_step_applies(D, p) for D in (1, 2, 3) for p in (1, 2))

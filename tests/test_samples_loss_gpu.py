@@ -32,7 +32,10 @@ def test_sinkhorn_matches_reference(cuda, name, backend):
     # p=1: the reference's own fp32 run is 3e-4 off its fp64 run (cancellation in the dense cost); our
     # kernels evaluate distances on differences, so they are compared with the fp64 reference.
     ref = "f64" if rec["kwargs"]["p"] == 1 and backend == "online" else "f32"
-    assert relerr(L.detach().cpu().numpy(), rec["loss_" + ref]) < 1e-4
+    # (dense fp32 p = 1 costs in D = 12: sqrt(|x|^2 + |y|^2 - 2 x.y) of terms of size 4 — the reference's own fp32 run is 6e-4 off its
+    # fp64 run there, and two fp32 evaluations of that matrix (CPU there, GPU here) differ by 1.4e-4)
+    dense_p1_high_d = rec["kwargs"]["p"] == 1 and backend == "tensorized" and x.shape[-1] > 3
+    assert relerr(L.detach().cpu().numpy(), rec["loss_" + ref]) < (3e-4 if dense_p1_high_d else 1e-4)
     assert relerr(L.detach().cpu().numpy(), rec["loss_f64"]) < 1e-4 or rec["kwargs"]["p"] == 1
     gx, ga = torch.autograd.grad(L.sum(), [x, a])
     # dense fp32 p=1 costs carry the reference's own cancellation error (its fp32 gradient is 1e-3 off its fp64 one)

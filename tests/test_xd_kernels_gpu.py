@@ -117,9 +117,11 @@ def test_softmin_batched_bf16_and_fused_step(cuda):
     first = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), None, None, damping).cpu().numpy()
     ref1 = damping * np.stack([oracle_c.softmin(eps, x[b], y[b], logw[b], 2) for b in range(B)])
     assert np.abs(first - ref1).max() < _tol(ref1, D)
-    # p = 1 has no fused kernel beyond D = 3, nothing has beyond D = 16, and NO_MFMA / DIRECT switch the matrix-core kernel off:
-    # hip.sinkhorn_step then composes the soft-min kernel with torch arithmetic (round 3 raised NotImplementedError here)
-    assert not hip.fused_step_applies(D, 1) and not hip.fused_step_applies(17, 2) and not hip.fused_step_applies(D, 2, hip.FLAG_NO_MFMA)
+    # nothing has a fused kernel beyond D = 16 (nor block-sparse p = 1 beyond D = 3), and NO_MFMA / DIRECT switch the matrix-core kernels
+    # off: hip.sinkhorn_step then composes the soft-min kernel with torch arithmetic (round 3 raised NotImplementedError here);
+    # dense p = 1 is one launch since round 5 (glhip_dist_xd.h) and must agree with the composition all the same
+    assert hip.fused_step_applies(D, 1) and not hip.fused_step_applies(D, 1, 0, True)
+    assert not hip.fused_step_applies(17, 2) and not hip.fused_step_applies(D, 2, hip.FLAG_NO_MFMA)
     for kw in (dict(p=1), dict(flags=hip.FLAG_NO_MFMA), dict(flags=hip.FLAG_DIRECT)):
         p = kw.get("p", 2)
         want = 0.5 * (_t(prev, cuda) + damping * hip.softmin(eps, xt, yt, _t(logw + pot / np.float32(eps), cuda), **kw))
@@ -344,3 +346,57 @@ def test_block_sparse_gradients_transposed_kernel(cuda, D, flags):
     (gk,) = torch.autograd.grad(k, [xg], grad_outputs=_t(g, cuda))
     assert relerr(k.detach().cpu().numpy(), oracle_c.kconv("gaussian", x, y, v, blur, ranges=tup)) < 1e-4
     assert relerr(gk.cpu().numpy(), oracle_c.kconv_grad_x("gaussian", x, y, v, g, blur, ranges=tup)) < 1e-4
+
+
+# ---- round 5: the distance reductions of 4 <= D <= 16 on the matrix cores (csrc/glhip_dist_xd.h) ---------------------------------
+
+@pytest.mark.parametrize("D", XD)
+@pytest.mark.parametrize("N,M,B", [(300, 257, None), (1030, 2100, None), (1, 1, None), (5, 3000, None), (260, 300, 3)])
+def test_distance_reductions_xd_vs_oracle(cuda, D, N, M, B):
+    """Soft-min p = 1 (plain and fused half-step), laplacian and energy products: squared distances from the MFMA chain, with coincident
+    and near pairs (the exact path; the debiasing terms of a loss are x against x), -inf dual values, batches, column splits or not —
+    against the float64 C oracle, and the one-thread-per-row kernel (GLHIP_FLAG_NO_MFMA) as a second opinion."""
+    x, y, h = _clouds(7 * D + N + M, N, M, D, B)
+    k = min(N, M) // 3
+    y[..., :k, :] = x[..., :k, :]                       # coincident pairs: the floor of utils.py:61
+    y[..., k:2 * k, :] = x[..., k:2 * k, :] + 3e-5       # near pairs
+    if M > 11:
+        h[..., ::11] = -np.inf
+    v = (np.random.default_rng(1).random(h.shape) / M).astype(np.float32)
+    eps, blur = 0.05, 0.2
+    bs = range(B) if B is not None else [None]
+    sel = (lambda a, b: a if b is None else a[b])
+    ref_f = np.stack([oracle_c.softmin(eps, sel(x, b), sel(y, b), sel(h, b), 1) for b in bs]).reshape(h.shape[:-1] + (N,))
+    ref_l = np.stack([oracle_c.kconv("laplacian", sel(x, b), sel(y, b), sel(v, b), blur) for b in bs]).reshape(ref_f.shape)
+    ref_e = np.stack([oracle_c.kconv("energy", sel(x, b), sel(y, b), sel(v, b), blur) for b in bs]).reshape(ref_f.shape)
+    xt, yt, ht, vt = (_t(a, cuda) for a in (x, y, h, v))
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):
+        tol = 1 if flags != hip.FLAG_NO_MFMA else 12      # the generic kernel sums |x - y|^2 coordinate by coordinate in fp32
+        f = hip.softmin(eps, xt, yt, ht, p=1, flags=flags).cpu().numpy()
+        assert np.abs(f - ref_f).max() < tol * 2e-6 * max(1.0, np.abs(ref_f).max()), flags
+        assert relerr(hip.kernel_conv("laplacian", xt, yt, vt, blur, flags=flags).cpu().numpy(), ref_l) < tol * 5e-6, flags
+        assert relerr(hip.kernel_conv("energy", xt, yt, vt, blur, flags=flags).cpu().numpy(), ref_e) < tol * 5e-6, flags
+    # fused half-step (dense p = 1: one launch)
+    rng = np.random.default_rng(3)
+    pot, prev = rng.standard_normal(h.shape).astype(np.float32) * 0.05, rng.standard_normal(ref_f.shape).astype(np.float32)
+    logw = np.where(np.isinf(h), -30.0, h).astype(np.float32)
+    got = hip.sinkhorn_step(eps, xt, yt, _t(logw, cuda), _t(pot, cuda), _t(prev, cuda), 0.8, p=1).cpu().numpy()
+    want = np.stack([oracle_c.softmin(eps, sel(x, b), sel(y, b), sel(logw, b) + sel(pot, b) / eps, 1) for b in bs]).reshape(ref_f.shape)
+    assert np.abs(got - 0.5 * (prev + 0.8 * want)).max() < 2e-6 * max(1.0, np.abs(want).max())
+
+
+def test_distance_reductions_xd_many_columns_and_self_term(cuda):
+    """70 001 columns (column splits + merge) and a self-term (x against x: every row has one coincident pair), D = 6, 100 sampled
+    rows against the chunked float64 oracle."""
+    D, N, M = 6, 9000, 70_001
+    x, y, h = _clouds(5, N, M, D)
+    rows = np.unique(np.r_[0, N - 1, np.random.default_rng(1).integers(0, N, 100)])
+    eps = 0.1
+    out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=1).cpu().numpy()
+    assert np.abs(out[rows] - o64.softmin(eps, x, y, h, p=1, rows=rows, device=cuda)).max() < 2e-6
+    hs = h[:N]
+    out = hip.softmin(eps, _t(x, cuda), _t(x, cuda), _t(hs, cuda), p=1).cpu().numpy()
+    assert np.abs(out[rows] - o64.softmin(eps, x, x, hs, p=1, rows=rows, device=cuda)).max() < 2e-6
+    v = (np.random.default_rng(2).random(N) / N).astype(np.float32)
+    e = hip.kernel_conv("energy", _t(x, cuda), _t(x, cuda), _t(v, cuda), 0.1).cpu().numpy()
+    assert relerr(e[rows], o64.kconv("energy", x, x, v, 0.1, rows=rows, device=cuda)) < 5e-6
