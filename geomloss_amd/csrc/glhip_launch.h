@@ -115,16 +115,18 @@ constexpr long kFwdSlots = 256 * 3;   // resident 8-wave workgroups of the forwa
 //   KIND 2: bf16x3 on 32x32x16 MFMAs, transposed blocks (glhip_softmin_x32.h) — the default.
 enum { FWD_F32 = 0, FWD_XDL16 = 1, FWD_X32 = 2 };
 
-template <int D, typename T, int KIND, int NW, bool SPARSE>
+template <int D, typename T, int KIND, int NW, bool SPARSE, int L = XL_BF16X3>
 void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp) {
-    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
+    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false, L>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
     else if (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
     else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
 
-template <int D, typename T, int KIND, int NW>
+template <int D, typename T, int KIND, int NW, int L = XL_BF16X3>
 void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                             const Scratch& sc, hipStream_t st) {
+    static_assert(L == XL_BF16X3 || KIND == FWD_X32, "the f16 x 2 layout exists on the 32x32x16 kernel only");
+    constexpr int NR = X32Layout<L>::NR;
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
     constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
     static_assert(kFwdRT == 2, "row tiling of the forward kernels");
@@ -147,7 +149,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
 
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
-    PackedCols pk{nullptr, (long)((M + 31) / 32) * 128};
+    PackedCols pk{nullptr, (long)((M + 31) / 32) * (32 * NR)};
     const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);   // either layout fits
     auto plan_pre = [&](int ns) {
         const size_t part_bytes = (((size_t)(ns > 1 ? ns : 0) * per_split) + 255) & ~(size_t)255;
@@ -157,16 +159,16 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         return true;
     };
     auto pack = [&]() {
-        if (n_ranges > 0) hipLaunchKernelGGL((pack_columns_kernel<D, T, false>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
-        else hipLaunchKernelGGL((pack_columns_kernel<D, T, true>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+        if (n_ranges > 0) hipLaunchKernelGGL((pack_columns_kernel<D, T, false, L>), dim3((M + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+        else hipLaunchKernelGGL((pack_columns_kernel<D, T, true, L>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
     };
 
     if constexpr (NW == 2) {    // block-sparse launches on row blocks of up to 64 points only (launch_softmin_mfma)
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
         } else {
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, false>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, PackedCols{nullptr, 0});
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, false, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, PackedCols{nullptr, 0});
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -174,7 +176,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (KIND != FWD_F32 && n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {
         // large dense problem: exactly 8 column splits, one per XCD (see workgroup_coords)
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
-        const int nx = (KIND == FWD_X32 && sc.prepack((double)B * N * M)) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit)
+        const int nx = (KIND == FWD_X32 && sc.prepack((double)B * N * M)) ? xcd_splits_prepacked((long)gx * B, M, kFwdSlots, fit, NR * 16.0)
                                                                           : xcd_splits((long)gx * B, M, kFwdSlots, fit);
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
@@ -183,9 +185,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
             sp.xcd_blocks = gx * B;
             if (plan_pre(nx)) {
                 pack();
-                hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+                hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true, L>), dim3((unsigned)total, 1, 1), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
             } else {
-                launch_fwd_kernel<D, T, KIND, NW, false>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
+                launch_fwd_kernel<D, T, KIND, NW, false, L>(dim3((unsigned)total, 1, 1), st, prm, rg, N, M, sp);
             }
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
             return;
@@ -194,9 +196,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (n_ranges > 0) {
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
         } else {
-            launch_fwd_kernel<D, T, KIND, NW, true>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
+            launch_fwd_kernel<D, T, KIND, NW, true, L>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -204,9 +206,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
         const int gx = (N + kRowsPerBlock - 1) / kRowsPerBlock;
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, false, 1, NW, true, L>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
         } else {
-            launch_fwd_kernel<D, T, KIND, NW, false>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
+            launch_fwd_kernel<D, T, KIND, NW, false, L>(dim3(gx, B, sp.n_splits), st, prm, rg, N, M, sp);
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -222,6 +224,15 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     // block-sparse with row blocks of a few hundred points (multiscale at 1e6: 0.27 vs 0.30 s); 4 wavefronts when
     // every workgroup packs its own tiles or the row blocks are small, where more, smaller workgroups win.
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
+    if constexpr (KIND == FWD_X32) {
+        if (sc.h2) {      // GLHIP_FLAG_F16X2: the same kernel on the f16 x 2 layout (one MFMA per block); same workgroup shapes
+            if (n_ranges > 0 && sc.small_rows && !forced_nw) launch_softmin_mfma_nw<D, T, FWD_X32, 2, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
+            else if (forced_nw ? forced_nw == 8 : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
+                launch_softmin_mfma_nw<D, T, FWD_X32, 8, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
+            else launch_softmin_mfma_nw<D, T, FWD_X32, 4, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
+            return;
+        }
+    }
     if (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (KIND == FWD_X32 && n_ranges > 0 && sc.small_rows && !forced_nw)
@@ -643,8 +654,9 @@ SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* 
 }
 
 // glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
-template <int D, typename T>
+template <int D, typename T, int L = XL_BF16X3>
 void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) {
+    constexpr int NR = X32Layout<L>::NR;
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;
     constexpr int NW = 4, kRows = NW * 32;
     int maxN = 0, minM = m.M[0];
@@ -673,7 +685,7 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     for (int k = 0; k < m.count; ++k) {
         pairs += (double)B * m.N[k] * m.M[k];
         maxM = m.M[k] > maxM ? m.M[k] : maxM;
-        m.pk[k] = PackedCols{nullptr, (long)((m.M[k] + 31) / 32) * 128};
+        m.pk[k] = PackedCols{nullptr, (long)((m.M[k] + 31) / 32) * (32 * NR)};
     }
     static const double pre_min = getenv("GLHIP_ITER4_PRE_MIN") ? atof(getenv("GLHIP_ITER4_PRE_MIN")) : 1e8;   // tuning knob
     bool pre = sc.ws && sc.allow_split && pairs >= pre_min;
@@ -687,10 +699,10 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
         }
     }
     if (pre) {
-        hipLaunchKernelGGL((pack_columns_multi_kernel<D, T>), dim3((maxM + 31 + kBlock) / kBlock, B, m.count), dim3(kBlock), 0, st, m);
-        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, true>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+        hipLaunchKernelGGL((pack_columns_multi_kernel<D, T, L>), dim3((maxM + 31 + kBlock) / kBlock, B, m.count), dim3(kBlock), 0, st, m);
+        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, true, L>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
     } else {
-        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, false>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+        hipLaunchKernelGGL((softmin_fwd_x32_multi_kernel<D, T, NW, false, L>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
     }
     if (sp.n_splits > 1)
         hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
@@ -714,6 +726,12 @@ int iter4_typed(const void* x, const void* y, const float* a_log, const float* b
         m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
     } else {
         m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+    }
+    if (sc.h2) {      // GLHIP_FLAG_F16X2: the iteration on the f16 x 2 layout, like the half-steps it replaces
+        if (D == 1) launch_iter4<1, T, XL_F16X2>(m, B, sc, st);
+        else if (D == 2) launch_iter4<2, T, XL_F16X2>(m, B, sc, st);
+        else launch_iter4<3, T, XL_F16X2>(m, B, sc, st);
+        return GLHIP_OK;
     }
     if (D == 1) launch_iter4<1, T>(m, B, sc, st);
     else if (D == 2) launch_iter4<2, T>(m, B, sc, st);
@@ -772,7 +790,8 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
             // Big dense launches only (pre-packed columns, XCD-aware grid): that is where it was measured to win — 87.1 -> 79.2 ms at
             // 1e6 x 1e6, 36.8 -> 35.0 ms per online loss at 1e5; batches of 4096 x 4096 problems lose 4 % to the x32 kernel's staging
             // (B = 256: 16.2 -> 17.0 ms per loss), and block-sparse launches keep the gathered pre-packed tiles of glhip_softmin_x32.h.
-            if (p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {
+            static const bool via_xd = getenv("GLHIP_H2_VIA_XD") ? atoi(getenv("GLHIP_H2_VIA_XD")) != 0 : true;      // A/B knob
+            if (via_xd && p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {
                 if (D == 1) launch_xd_l<XD_SOFTMIN, 1, T, SoftminFwdOp<1, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
                 else if (D == 2) launch_xd_l<XD_SOFTMIN, 2, T, SoftminFwdOp<2, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
                 else launch_xd_l<XD_SOFTMIN, 3, T, SoftminFwdOp<3, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);

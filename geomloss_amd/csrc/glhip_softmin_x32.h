@@ -18,11 +18,10 @@
 // Lazy max, speculative tile pass, tile-end check, exact redo, column splits and the merge are as in the 16x16 kernel.
 #pragma once
 
-#include "glhip_softmin_xdl.h"
+#include "glhip_klayout.h"
 
 namespace glhip {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma_x32(const uint4& a, const uint4& b, const f32x16& c) {
     Pack16 pa, pb;
@@ -71,7 +70,11 @@ __device__ __forceinline__ float sum_exp2_16(const f32x16& v, float m) {
 
 // One column of the cost matrix as the four 16-byte MFMA records of the layout above (coordinates relative to
 // `centre`), written `stride` records apart starting at `base` (K block 0).
-template <int D, typename T>
+// records per column: 4 (three coordinate blocks + the scalar block) in the bf16 x 3 layout above; 2 in the f16 x 2 layout of
+// glhip_klayout.h (GLHIP_FLAG_F16X2: 3 D + 6 <= 15 K slots — ONE MFMA per 32 x 32 block, half the LDS and packed-column bytes)
+template <int L> struct X32Layout { static constexpr int NR = (L == XL_F16X2) ? 2 : 4; };
+
+template <int D, typename T, int L = XL_BF16X3>
 __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long col, bool valid, const float (&centre)[D],
                                             uint4* base, int stride) {
     float rec[4] = {0.f, 0.f, 0.f, kNegBig};
@@ -86,6 +89,16 @@ __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long co
         }
         rec[3] = __builtin_fmaf(-0.5f * prm.s2, n2, dual_entry(prm, col) * kLog2e);
     }
+    if constexpr (L == XL_F16X2) {      // both sides carry sqrt(s); exponents below the floor are the floor (glhip_klayout.h)
+        const float q = __builtin_sqrtf(prm.s2);
+        float ys[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) ys[d] = rec[d] * q;
+        const float H = __builtin_fmaxf(rec[3], kH2Floor);
+        base[0] = xd_record_of<D, false, L>(0, H, ys);
+        base[stride] = xd_record_of<D, false, L>(1, H, ys);
+        return;
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) base[d * stride] = (d < D) ? pack_y(rec[d]) : uint4{0u, 0u, 0u, 0u};
     base[3 * stride] = pack_h1(rec[3]);
@@ -97,32 +110,33 @@ __device__ __forceinline__ void pack_column(const SoftminParams<T>& prm, long co
 // cluster-sorted clouds (block-sparse mode) the per-workgroup centre of the on-the-fly path is more accurate, the global one
 // has the accuracy of the dense launches (absolute error of a potential ~ 2^-24 diam^2, independent of eps).
 struct PackedCols {
-    uint4* rec;     // dense launches (GROUPED): [B][ceil(M/32)][4 K blocks][32 columns] — the LDS tile layout, so a tile
+    uint4* rec;     // dense launches (GROUPED): [B][ceil(M/32)][NR K blocks][32 columns] (NR = 4, or 2 in the f16 x 2 layout) — the LDS tile layout, so a tile
                     //   (which starts on a group boundary there) is staged by a linear, fully coalesced copy;
                     // block-sparse launches: [M][4 K blocks] — tiles start at arbitrary columns
-    long stride;    // GROUPED: records per batch item = ceil(M/32) * 128
+    long stride;    // GROUPED: records per batch item = ceil(M/32) * 32 NR
 };
 
-template <int D, typename T, bool GROUPED>
+template <int D, typename T, bool GROUPED, int L = XL_BF16X3>
 __global__ void __launch_bounds__(kBlock)
 pack_columns_kernel(SoftminParams<T> prm, int N, int M, PackedCols pk) {
+    constexpr int NR = X32Layout<L>::NR;
     const int b = blockIdx.y;
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= (GROUPED ? ((M + 31) & ~31) : M)) return;
     float centre[D];
     launch_centre<D, T>(prm.x, b, N, centre);
-    if (GROUPED) pack_column<D, T>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * 128 + (j & 31), 32);
-    else pack_column<D, T>(prm, (long)b * M + j, true, centre, pk.rec + ((long)b * M + j) * 4, 1);
+    if (GROUPED) pack_column<D, T, L>(prm, (long)b * M + j, j < M, centre, pk.rec + b * pk.stride + (j >> 5) * (32 * NR) + (j & 31), 32);
+    else pack_column<D, T, L>(prm, (long)b * M + j, true, centre, pk.rec + ((long)b * M + j) * NR, 1);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // register-friendly 16-byte value (HIP's uint4 is a struct)
 
 // registers <- this thread's share of the next tile.  GROUPED: records r = tid, tid + THREADS, ... of the contiguous
 // run `src` (cnt records); otherwise the 4 records of columns t = tid, tid + THREADS, ... (n real columns at `src`).
-template <int PER, int THREADS, bool GROUPED>
+template <int PER, int THREADS, bool GROUPED, int NR = 4>
 __device__ __forceinline__ void fetch_records(u32x4 (&pre)[PER], const uint4* src, int n, int tid) {
     if (GROUPED) {
-        const int cnt = ((n + 31) & ~31) * 4;
+        const int cnt = ((n + 31) & ~31) * NR;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int r = tid + k * THREADS;
@@ -130,11 +144,11 @@ __device__ __forceinline__ void fetch_records(u32x4 (&pre)[PER], const uint4* sr
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < PER / 4; ++k) {
+        for (int k = 0; k < PER / NR; ++k) {
             const int t = tid + k * THREADS;
-            const u32x4* col = reinterpret_cast<const u32x4*>(src + (long)(t < n ? t : 0) * 4);
+            const u32x4* col = reinterpret_cast<const u32x4*>(src + (long)(t < n ? t : 0) * NR);
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) pre[k * 4 + kb] = col[kb];
+            for (int kb = 0; kb < NR; ++kb) pre[k * NR + kb] = col[kb];
         }
     }
 }
@@ -205,7 +219,7 @@ constexpr int fwd_tile(int NW) { return NW == 2 ? 256 : kTileX; }
 
 // The work of one workgroup: row block bx of batch item b, column split `split`.  tileX: kTile * 4 records of LDS,
 // [column group of 32][K block][column], one 16-byte record per (column, K block).
-template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE>
+template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE, int L = XL_BF16X3>
 __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm, const Ranges& rg, int N, int M,
                                                      const SplitInfo& sp, const PackedCols& pk, int bx, int b, int split,
                                                      uint4* tileX) {
@@ -213,8 +227,12 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
     constexpr int kTile = fwd_tile(NW);
-    constexpr int kPer = (kTile * 4) / kThreads;   // PRE: records one thread moves per tile
-    static_assert((kTile * 4) % kThreads == 0, "tile / workgroup shape");
+    constexpr int NR = X32Layout<L>::NR;            // records per column
+    constexpr bool H2 = (L == XL_F16X2);
+    constexpr int GS = 32 * NR;                     // records per column group of 32
+    constexpr int kPer = (kTile * NR) / kThreads;   // PRE: records one thread moves per tile
+    static_assert((kTile * NR) % kThreads == 0, "tile / workgroup shape");
+    constexpr float kFloor = H2 ? kH2Floor : kMinusHuge;      // the running maximum of a row that has seen no mass yet
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -243,14 +261,23 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
             const int i = min(wave_row0 + rt * 32 + l31, row_end - 1);
             float xi[D];
             load_point<D, T>(prm.x, (long)b * N + i, xi);
-            float a[3] = {0.f, 0.f, 0.f};
+            if constexpr (H2) {      // one operand: record `half` of [k,k,k,n1,n2,n3 | a_hi,a_hi,a_lo per coordinate], n = 0 for now
+                float a[D];
+                const float q = __builtin_sqrtf(prm.s2);
 #pragma unroll
-            for (int d = 0; d < D; ++d) a[d] = (xi[d] - centre[d]) * prm.s2;
-            const uint4 z = uint4{0u, 0u, 0u, 0u};
-            const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : z, p2 = (D > 2) ? pack_a(a[2]) : z;
-            Xlo[rt] = half ? p1 : p0;
-            Xhi[rt] = half ? kOnes : p2;
-            m[rt] = kMinusHuge;
+                for (int d = 0; d < D; ++d) a[d] = (xi[d] - centre[d]) * q;
+                Xlo[rt] = select_u4(half != 0, xd_record_of<D, true, L>(1, 0.f, a), xd_record_of<D, true, L>(0, 0.f, a));
+                Xhi[rt] = Xlo[rt];
+            } else {
+                float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < D; ++d) a[d] = (xi[d] - centre[d]) * prm.s2;
+                const uint4 z = uint4{0u, 0u, 0u, 0u};
+                const uint4 p0 = pack_a(a[0]), p1 = (D > 1) ? pack_a(a[1]) : z, p2 = (D > 2) ? pack_a(a[2]) : z;
+                Xlo[rt] = half ? p1 : p0;
+                Xhi[rt] = half ? kOnes : p2;
+            }
+            m[rt] = kFloor;
             ssum[rt] = 0.f;
         }
         const bool wave_active = wave_row0 < row_end;
@@ -258,10 +285,20 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 
         // PRE: the records of the next tile are fetched into registers while the current tile is consumed
         u32x4 pre[kPer];
-        const uint4 nh = pack_h1(kNegBig);
-        const u32x4 neutral_h = u32x4{nh.x, nh.y, nh.z, nh.w};
+        // a padding column: zero coordinates, H = "minus infinity" of the layout
+        u32x4 neutral[NR];
+        {
+            const float zeros[D] = {};
+#pragma unroll
+            for (int kb = 0; kb < NR; ++kb) {
+                uint4 r = uint4{0u, 0u, 0u, 0u};
+                if constexpr (H2) r = xd_record_of<D, false, L>(kb, kH2Floor, zeros);
+                else if (kb == 3) r = pack_h1(kNegBig);
+                neutral[kb] = u32x4{r.x, r.y, r.z, r.w};
+            }
+        }
         auto tile_src = [&](int j0) {   // first record of the tile starting at column j0 in the packed buffer
-            return SPARSE ? pk.rec + ((long)b * M + j0) * 4 : pk.rec + b * pk.stride + (long)(j0 >> 5) * 128;
+            return SPARSE ? pk.rec + ((long)b * M + j0) * NR : pk.rec + b * pk.stride + (long)(j0 >> 5) * GS;
         };
         TileCursor cur;
         cur.q = q_begin + (SPARSE ? split : 0);
@@ -270,15 +307,15 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         const int pieces = sp.gather ? kTile : 1;
         constexpr bool GATHER = SPARSE && PRE;   // pre-packed: the gathered tile is fetched into registers one tile ahead
         constexpr bool GATHER_NOW = SPARSE && !PRE;   // packed on the fly: gathered when it is staged
-        constexpr int kCols = kPer / 4;          // columns a thread moves per tile
+        constexpr int kCols = kPer / NR;         // columns a thread moves per tile
         int gcols[kCols], gn = 0;                // GATHER: the columns behind `pre`, and how many real ones the fetched tile holds
         TileCursor gnext = cur;                  // GATHER: the cursor after the fetched tile
         auto fetch_gathered = [&]() {
 #pragma unroll
             for (int k = 0; k < kCols; ++k) {
-                const u32x4* col = reinterpret_cast<const u32x4*>(pk.rec + ((long)b * M + max(gcols[k], 0)) * 4);
+                const u32x4* col = reinterpret_cast<const u32x4*>(pk.rec + ((long)b * M + max(gcols[k], 0)) * NR);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) pre[k * 4 + kb] = col[kb];
+                for (int kb = 0; kb < NR; ++kb) pre[k * NR + kb] = col[kb];
             }
         };
         if (GATHER) {
@@ -287,7 +324,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 fetch_gathered();
             }
         } else if (PRE && cur.q < q_end) {
-            fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(cur.j0), min(kTile, cur.je - cur.j0), tid);
+            fetch_records<kPer, kThreads, !SPARSE, NR>(pre, tile_src(cur.j0), min(kTile, cur.je - cur.j0), tid);
         }
 
         while (cur.q < q_end) {
@@ -311,18 +348,17 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 #pragma unroll
                     for (int k = 0; k < kPer; ++k) {
                         const int r = tid + k * kThreads;
-                        if (r < npad * 4) *reinterpret_cast<u32x4*>(&tileX[r]) = pre[k];
+                        if (r < npad * NR) *reinterpret_cast<u32x4*>(&tileX[r]) = pre[k];
                     }
                 } else if (PRE) {
 #pragma unroll
-                    for (int k = 0; k < kPer / 4; ++k) {
+                    for (int k = 0; k < kPer / NR; ++k) {
                         const int t = tid + k * kThreads;
                         if (t < npad) {
-                            u32x4* dst = reinterpret_cast<u32x4*>(&tileX[(t >> 5) * 128 + (t & 31)]);
+                            u32x4* dst = reinterpret_cast<u32x4*>(&tileX[(t >> 5) * GS + (t & 31)]);
                             const bool real = t < n;      // (gathered tiles fill their slots in order: the same test)
 #pragma unroll
-                            for (int kb = 0; kb < 3; ++kb) dst[kb * 32] = real ? pre[k * 4 + kb] : u32x4{0u, 0u, 0u, 0u};
-                            dst[96] = real ? pre[k * 4 + 3] : neutral_h;
+                            for (int kb = 0; kb < NR; ++kb) dst[kb * 32] = real ? pre[k * NR + kb] : neutral[kb];
                         }
                     }
                 }
@@ -333,16 +369,16 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                     }
                 } else if (PRE) {
                     if (nxt.q < q_end)
-                        fetch_records<kPer, kThreads, !SPARSE>(pre, tile_src(nxt.j0), min(kTile, nxt.je - nxt.j0), tid);
+                        fetch_records<kPer, kThreads, !SPARSE, NR>(pre, tile_src(nxt.j0), min(kTile, nxt.je - nxt.j0), tid);
                 } else if (GATHER_NOW) {
 #pragma unroll
                     for (int k = 0; k < kCols; ++k) {
                         const int t = tid + k * kThreads;
-                        if (t < npad) pack_column<D, T>(prm, (long)b * M + max(gcols[k], 0), t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)], 32);
+                        if (t < npad) pack_column<D, T, L>(prm, (long)b * M + max(gcols[k], 0), t < n, centre, &tileX[(t >> 5) * GS + (t & 31)], 32);
                     }
                 } else {
                     for (int t = tid; t < npad; t += kThreads)
-                        pack_column<D, T>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * 128 + (t & 31)], 32);
+                        pack_column<D, T, L>(prm, (long)b * M + j0 + t, t < n, centre, &tileX[(t >> 5) * GS + (t & 31)], 32);
                 }
                 cur = nxt;
                 __syncthreads();
@@ -350,18 +386,30 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 
                 const int nG = npad / 32;
                 int G0 = 0;
+                // one 32 x 32 block of exponents: column group G against row tile rt (`plain`: with n = 0, for the exact maxima)
+                auto block = [&](int G, int rt, bool plain) -> f32x16 {
+                    if constexpr (H2) {
+                        const uint4 xa = plain ? select_u4(half == 0, xd_with_n<L>(Xlo[rt], 0.f), Xlo[rt]) : Xlo[rt];
+                        return mfma_h32(tileX[G * GS + rec0], xa, zero16);
+                    } else {
+                        f32x16 u = mfma_x32(tileX[G * GS + rec0], Xlo[rt], zero16);
+                        return mfma_x32(tileX[G * GS + 64 + rec0], select_u4(plain && half, kOnes, Xhi[rt]), u);
+                    }
+                };
+                auto set_max = [&](int rt, float mx) {      // the running maximum enters through the K slots of the scalar item
+                    if constexpr (H2) Xlo[rt] = select_u4(half == 0, xd_with_n<L>(Xlo[rt], -mx), Xlo[rt]);
+                    else if (half) Xhi[rt] = pack_negmax(mx);
+                };
                 if (first_group) {   // exact maximum over the first 32 columns
-                    const uint4 ya = tileX[rec0], yb = tileX[64 + rec0];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        f32x16 u = mfma_x32(ya, Xlo[rt], zero16);
-                        u = mfma_x32(yb, Xhi[rt], u);
+                        const f32x16 u = block(0, rt, false);      // n = 0 so far
                         float um = max16(u);
                         um = fmaxf(um, __shfl_xor(um, 32, 64));
-                        um = fmaxf(um, kMinusHuge);
+                        um = fmaxf(um, kFloor);
                         m[rt] = um;
                         ssum[rt] = sum_exp2_16(u, um);
-                        if (half) Xhi[rt] = pack_negmax(um);
+                        set_max(rt, um);
                     }
                     first_group = false;
                     G0 = 1;
@@ -371,13 +419,8 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
                 for (int G = G0; G < nG; ++G) {
-                    const uint4 ya = tileX[G * 128 + rec0], yb = tileX[G * 128 + 64 + rec0];
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        f32x16 d = mfma_x32(ya, Xlo[rt], zero16);
-                        d = mfma_x32(yb, Xhi[rt], d);
-                        stmp[rt] += sum_exp2_16(d);
-                    }
+                    for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(block(G, rt, false));
                 }
                 float smax = stmp[0];
 #pragma unroll
@@ -385,11 +428,9 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 if (__any(!(smax < kSumThr))) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
                     for (int G = G0; G < nG; ++G) {
-                        const uint4 ya = tileX[G * 128 + rec0], yb = tileX[G * 128 + 64 + rec0];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) {
-                            f32x16 u = mfma_x32(ya, Xlo[rt], zero16);
-                            u = mfma_x32(yb, half ? kOnes : Xhi[rt], u);
+                            const f32x16 u = block(G, rt, true);
                             float um = max16(u);
                             um = fmaxf(um, __shfl_xor(um, 32, 64));
                             const float mnew = fmaxf(m[rt], um);
@@ -398,8 +439,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                         }
                     }
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        if (half) Xhi[rt] = pack_negmax(m[rt]);
+                    for (int rt = 0; rt < RT; ++rt) set_max(rt, m[rt]);
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
@@ -410,7 +450,8 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         if (wave_active) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // both halves carry the same max
+                float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // both halves carry the same max
+                if (H2 && m[rt] <= kH2Floor * 0.98f) s = 0.f;      // a row still at the floor has seen no mass (glhip_softmin_xd.h)
                 const int i = wave_row0 + rt * 32 + l31;
                 if (half == 0 && i < row_end) {
                     float xi[D];
@@ -435,13 +476,13 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
     }
 }
 
-template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false>
+template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false, int L = XL_BF16X3>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
-    __shared__ uint4 tileX[fwd_tile(NW) * 4];
+    __shared__ uint4 tileX[fwd_tile(NW) * X32Layout<L>::NR];
     int bx, b, split;
     workgroup_coords(sp, bx, b, split);
-    softmin_fwd_x32_body<D, T, SPARSE, RT, NW, PRE>(prm, rg, N, M, sp, pk, bx, b, split, tileX);
+    softmin_fwd_x32_body<D, T, SPARSE, RT, NW, PRE, L>(prm, rg, N, M, sp, pk, bx, b, split, tileX);
 }
 
 // Up to four independent dense reductions in ONE launch — the four soft-mins of a Sinkhorn iteration
@@ -456,7 +497,7 @@ struct SoftminMulti {
 };
 
 // the columns of all the problems of a multi launch as packed records, once (grid: column blocks x batch x problem)
-template <int D, typename T>
+template <int D, typename T, int L = XL_BF16X3>
 __global__ void __launch_bounds__(kBlock)
 pack_columns_multi_kernel(SoftminMulti<T> m) {
     const int k = blockIdx.z, b = blockIdx.y;
@@ -465,13 +506,13 @@ pack_columns_multi_kernel(SoftminMulti<T> m) {
     if (N == 0 || j >= ((M + 31) & ~31)) return;
     float centre[D];
     launch_centre<D, T>(m.p[k].x, b, N, centre);
-    pack_column<D, T>(m.p[k], (long)b * M + j, j < M, centre, m.pk[k].rec + b * m.pk[k].stride + (j >> 5) * 128 + (j & 31), 32);
+    pack_column<D, T, L>(m.p[k], (long)b * M + j, j < M, centre, m.pk[k].rec + b * m.pk[k].stride + (j >> 5) * (32 * X32Layout<L>::NR) + (j & 31), 32);
 }
 
-template <int D, typename T, int NW, bool PRE = false>
+template <int D, typename T, int NW, bool PRE = false, int L = XL_BF16X3>
 __global__ void __launch_bounds__(NW * 64)
 softmin_fwd_x32_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
-    __shared__ uint4 tileX[kTileX * 4];
+    __shared__ uint4 tileX[kTileX * X32Layout<L>::NR];
     const int k = blockIdx.z / sp.n_splits;
     const int split = blockIdx.z - k * sp.n_splits;
     const int N = m.N[k], M = m.M[k];
@@ -479,7 +520,7 @@ softmin_fwd_x32_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
     SplitInfo spk = sp;
     spk.workspace += k * m.ws_stride;
     spk.split_stride = (long)gridDim.y * N * 2;   // this problem's own row count
-    softmin_fwd_x32_body<D, T, false, 1, NW, PRE>(m.p[k], Ranges{nullptr, nullptr, nullptr}, N, M, spk, m.pk[k],
+    softmin_fwd_x32_body<D, T, false, 1, NW, PRE, L>(m.p[k], Ranges{nullptr, nullptr, nullptr}, N, M, spk, m.pk[k],
                                                   (int)blockIdx.x, (int)blockIdx.y, split, tileX);
 }
 

@@ -746,6 +746,7 @@ class Iter4Plan:
                     o += B * n
                 self.sets.append(bufs)
         self.turn = 0
+        self.extra_flags = 0      # per-call flags of the owner (GLHIP_FLAG_F16X2 where the temperature allows: sinkhorn_samples._HipSoftmin)
         self.fixed = (xb.data_ptr(), yb.data_ptr(), self.a_log.data_ptr(), bl.data_ptr())
         self.dtype = _dtype_code(xb)
 
@@ -770,7 +771,7 @@ class Iter4Plan:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.glhip_sinkhorn_iter4(*self.fixed, *old, *new, B, N, M, D, float(eps), float(damping), 2, self.dtype,
                                            1 if pots is None else (2 if last else 0), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
-                                           self.flags, stream)
+                                           self.flags | self.extra_flags, stream)
         _check(rc, self.lib)
         return tuple(t.view(sh) for t, sh in zip(outs, self.shapes))
 

@@ -203,13 +203,19 @@ class _HipSoftmin:
     def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):
         """All simultaneous updates of one iteration in one launch (``glhip_sinkhorn_iter4``), or None (see _iter4_plan)."""
         plan = self._iter4_plan(C_xy, a_log, b_log, debias, create=True)
-        return None if plan is None else plan.run(eps, damping, pots)
+        if plan is None:
+            return None
+        plan.extra_flags = self._flags(eps)
+        return plan.run(eps, damping, pots)
 
     def last4(self, eps, C_xy, C_yx, a_log, b_log, pots, damping, debias, create=False):
         """The differentiable, non-averaged last update of every potential as one forward launch (and one autograd node);
         None when :meth:`iter4` did not run this loop (unless ``create``)."""
         plan = self._iter4_plan(C_xy, a_log, b_log, debias, create=create)
-        return None if plan is None else hip.sinkhorn_last4(plan, C_xy[0], C_yx[0], eps, damping, pots)
+        if plan is None:
+            return None
+        plan.extra_flags = self._flags(eps)
+        return hip.sinkhorn_last4(plan, C_xy[0], C_yx[0], eps, damping, pots)
 
 
 # hipGraph mode for the launch-bound regime (small clouds): the whole autograd-free annealing loop of the online
