@@ -125,8 +125,14 @@ def cpu_baseline(budget_s=10.0):
 
     v1, t1, n1, c1, l1 = timed(x1, y1, 9, budget_s * 0.5)
     v5, t5, n5, c5, _ = timed(x5, y5, 3, budget_s * 0.5)
+    all_cores = None
+    if best_threads != cores:      # north star: "core count stated" — the same sample with every logical core as well
+        torch.set_num_threads(cores)
+        va, ta, na, _, _ = timed(x1, y1, 5, 3.0)
+        all_cores = {"value": va, "unit": "pairs/s", "cores": cores, "seconds": ta, "runs": na}
+        torch.set_num_threads(best_threads)
     return {
-        "value": v1, "unit": "pairs/s", "cores": best_threads, "kind": "port",
+        "value": v1, "unit": "pairs/s", "cores": best_threads, "cores_total": cores, "all_cores": all_cores, "kind": "port",
         "sample": f"BASELINE configs[0] exactly: PyTorch-CPU tensorized SamplesLoss('sinkhorn',p=2,blur=.05) forward, N=M=2000 2D fp32, "
                   f"seed 0 ({c1} dense soft-mins, median of {n1} runs, {t1:.3f} s each, loss {l1:.7e}; reference value 1.9925134e-04); "
                   f"{best_threads} torch threads = fastest of a sweep on a host with {cores} logical cores. "
