@@ -121,6 +121,29 @@ def native_clustering_applies(x, labels=None):
             and x.dtype in (torch.float32, torch.bfloat16) and hip.library_available())
 
 
+def clusterize_device_many(clouds, scale, pre_div=1.0):
+    """:func:`clusterize_device` for several weighted clouds ``[(a, x), ...]`` with ONE host round trip for all their cluster counts
+    (the two measures of a two-scale loss: one synchronisation instead of two)."""
+    from . import hip
+    pending = []
+    for a, x in clouds:
+        xd = x.detach().contiguous()
+        ad = None if a is None else a.detach().float().contiguous().view(-1)
+        need_graph = torch.is_grad_enabled() and (x.requires_grad or (a is not None and a.requires_grad))
+        pending.append((a, x, need_graph, hip.grid_cluster_raw(xd, ad, scale, pre_div, gather=not need_graph, defer=True)))
+    counts = hip.read_back(*[p[3][0] for p in pending])
+    out = []
+    for (a, x, need_graph, (_, finish)), values in zip(pending, counts):
+        perm32, xs, ws, ranges, cents, w_c = finish(values)
+        perm = perm32.long()
+        if need_graph:
+            xs, ws = x[perm], (None if a is None else a[perm])
+        elif a is not None and a.dtype != torch.float32:
+            ws = ws.to(a.dtype)
+        out.append((w_c, ws, cents.to(x.dtype), xs, ranges, perm))
+    return out
+
+
 def clusterize_device(a, x, scale, pre_div=1.0):
     """``grid_cluster`` + ``cluster_ranges_centroids`` + ``sort_clusters`` in one call of ``glhip_grid_cluster``.
 
@@ -140,13 +163,14 @@ def clusterize_device(a, x, scale, pre_div=1.0):
     return w_c, ws, cents.to(x.dtype), xs, ranges, perm
 
 
-def kept_pairs_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
-    """Pairs of points the keep rule of :func:`block_ranges_device` retains (same arguments), counted without building the pattern."""
+def kept_pairs_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2, defer=False):
+    """Pairs of points the keep rule of :func:`block_ranges_device` retains (same arguments), counted without building the pattern
+    (``defer``: the device tensor of the three counts, for a shared ``hip.read_back``)."""
     from . import hip
     code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
     f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
     return hip.kept_pairs_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),
-                              ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p)
+                              ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p, defer=defer)
 
 
 def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):

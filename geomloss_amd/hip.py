@@ -386,12 +386,24 @@ def softmin_dense_fwd_raw(C, h, eps):
     return out
 
 
-def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True):
+def read_back(*tensors):
+    """ONE host round trip for several small device tensors (cluster counts, kept-pair counts): their values as lists of ints."""
+    flat = torch.cat([t.reshape(-1).to(torch.int64) for t in tensors]).tolist()
+    out, o = [], 0
+    for t in tensors:
+        out.append([int(v) for v in flat[o:o + t.numel()]])
+        o += t.numel()
+    return out
+
+
+def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True, defer=False):
     """Voxel clustering on the device (``glhip_grid_cluster``).  x (N,D) fp32|bf16 contiguous CUDA, weights (N,) fp32 or None.
 
     Returns ``(perm, x_sorted, w_sorted, ranges, centroids, weights_c)``: ``perm`` (N,) int32; ``x_sorted`` / ``w_sorted`` the
     cloud in cluster order (None without ``gather``); ``ranges`` (C,2) int32, ``centroids`` (C,D) fp32 of ``x / pre_div``,
-    ``weights_c`` (C,) fp32.  One host read-back (the cluster count) sizes the outputs."""
+    ``weights_c`` (C,) fp32.  One host read-back (the cluster count) sizes the outputs — with ``defer`` the launch is queued and
+    ``(count tensor, finish)`` comes back instead: the caller reads the counts of several clusterings in one round trip
+    (:func:`read_back`) and calls ``finish(count values)`` for the tuple above."""
     lib = load_library()
     N, D = x.shape
     dev = x.device
@@ -410,10 +422,15 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True):
                                     ptr(x_sorted), ptr(w_sorted), ranges.data_ptr(), cents.data_ptr(), w_c.data_ptr(),
                                     count.data_ptr(), ws.data_ptr(), nbytes, _stream(x))
     _check(rc, lib)
-    C, overflow = (int(v) for v in count.tolist())      # the one host round trip
-    if overflow:
-        raise ValueError("geomloss_amd: the voxel grid has more than 2^21 cells along an axis; use a larger cluster_scale.")
-    return perm, x_sorted, w_sorted, ranges[:C], cents[:C], w_c[:C]
+
+    def finish(values):
+        C, overflow = values
+        if overflow:
+            raise ValueError("geomloss_amd: the voxel grid has more than 2^21 cells along an axis; use a larger cluster_scale.")
+        return perm, x_sorted, w_sorted, ranges[:C], cents[:C], w_c[:C]
+    if defer:
+        return count, finish
+    return finish(read_back(count)[0])      # the one host round trip
 
 
 _RANGES_WORST_CASE_MAX = 1 << 20     # intervals: up to here the worst-case buffers (2 x 8 MB) are cheaper than a host round trip
@@ -459,10 +476,10 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
 
-def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2, defer=False):
     """``(kept pairs of points, sum of squared row-cluster sizes, sum of squared column-cluster sizes)`` for the keep rule of
     :func:`block_ranges_raw` (``glhip_block_ranges_kept_pairs``; same arguments): one launch and one 24-byte read-back, no intervals
-    built."""
+    built.  ``defer``: the (3,) int64 device tensor instead, for a shared :func:`read_back`."""
     lib = load_library()
     Cr, D = rows.shape
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
@@ -471,7 +488,7 @@ def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
         _check(lib.glhip_block_ranges_kept_pairs(int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, cols.shape[0], D, int(p),
                                                  float(thr), ranges_rows.data_ptr(), ranges_cols.data_ptr(), kept.data_ptr(),
                                                  _stream(rows)), lib)
-    return tuple(int(v) for v in kept.tolist())
+    return kept if defer else tuple(read_back(kept)[0])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -21,8 +21,8 @@ import numpy as np
 import torch
 
 from . import hip
-from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, from_matrix, grid_cluster,
-                      kept_pairs_device, native_clustering_applies, swap_axes)
+from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, clusterize_device_many, from_matrix,
+                      grid_cluster, kept_pairs_device, native_clustering_applies, swap_axes)
 from .sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
@@ -400,10 +400,27 @@ def _goes_dense(truncate, eps, eps_last, N, M, Cr, Cc, kept_pairs):
     return dense_is_cheaper(kept, N, M, Cr, Cc), sq_rows <= _SMALL_ROW_BLOCK * N, sq_cols <= _SMALL_ROW_BLOCK * M
 
 
-def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False, eps_last=None):
+def kernel_truncation_prefetch(calls, eps, truncate=None, cost=None, eps_last=None):
+    """The keep-rule counts that the :func:`kernel_truncation` calls of one coarse-to-fine jump will ask for — the cross term and the
+    two debiasing terms — queued together and read back in ONE host round trip.  ``calls``: [(C, C_t, f, g), ...] as they will be
+    passed to kernel_truncation; returns a list of ``kept`` triples (None where the call would not count)."""
+    if truncate is None or _DENSE_SWITCH in ("0", "always") or eps_last is None or truncate * eps / eps_last < _DENSE_SWITCH_MIN_EXPONENT:
+        return [None] * len(calls)
+    native_p = getattr(cost, "glhip_exponent", None)
+    pending = []
+    for C, C_t, f, g in calls:
+        x, y = C[0], C_t[0]
+        ok = native_p is not None and native_clustering_applies(x)
+        pending.append(kept_pairs_device("dual_slack", x, y, f, g, C[2], C[3], truncate * eps, p=native_p, defer=True) if ok else None)
+    live = [t for t in pending if t is not None]
+    values = iter(hip.read_back(*live)) if live else iter(())
+    return [None if t is None else tuple(next(values)) for t in pending]
+
+
+def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, cost=None, verbose=False, eps_last=None, kept=None):
     """Keeps the fine blocks whose coarse dual slack allows mass: f_i + g_j > C_ij - truncate * eps (``:493-530``).
     ``eps_last`` (not in the reference): the last temperature of the loop, which lets the fine level stay dense where that is cheaper
-    and changes nothing (see above); None: always the pattern."""
+    and changes nothing (see above); None: always the pattern.  ``kept``: the counts of :func:`kernel_truncation_prefetch`."""
     if truncate is None:
         return C_xy_, C_yx_
     x, yd, ranges_x, ranges_y, _ = C_xy
@@ -414,7 +431,7 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     if native_p is not None and native_clustering_applies(x):
         rule = ("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps)
         dense, small_x, small_y = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0],
-                                              lambda: kept_pairs_device(*rule, p=native_p))
+                                              (lambda: kept) if kept is not None else (lambda: kept_pairs_device(*rule, p=native_p)))
         ranges_xy_ = None if dense else block_ranges_device(*rule, p=native_p)
         if ranges_xy_ is not None:
             ranges_xy_.small_i, ranges_xy_.small_j = small_x, small_y
@@ -447,6 +464,13 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     return (x_, yd_, ranges_x_, ranges_y_, ranges_xy_), (y_, xd_, ranges_y_, ranges_x_, swap_axes(ranges_xy_))
 
 
+def _truncation(verbose, eps_last):
+    """kernel_truncation as the loop calls it, plus its `prefetch` hook (sinkhorn_divergence.sinkhorn_loop: one read-back per jump)."""
+    fn = partial(kernel_truncation, verbose=verbose, eps_last=eps_last)
+    fn.prefetch = partial(kernel_truncation_prefetch, eps_last=eps_last)
+    return fn
+
+
 def extrapolate_samples(f_ba, g_ab, eps, damping, C_xy, b_log, C_xy_, softmin=None):
     """Coarse-to-fine update of a potential: one soft-min of the fine points against the coarse measure (``:533-544``)."""
     yd = C_xy[1]  # coarse source points
@@ -475,8 +499,11 @@ def sinkhorn_multiscale(
     # voxel size: about 2000 cells over the bounding box
     if cluster_scale is None:
         cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
-    [a_c, a], [x_c, x], [ranges_x], perm_x = clusterize(a, x, scale=cluster_scale, labels=labels_x)
-    [b_c, b], [y_c, y], [ranges_y], perm_y = clusterize(b, y, scale=cluster_scale, labels=labels_y)
+    if native_clustering_applies(x, labels_x) and native_clustering_applies(y, labels_y):      # both clusterings, one host round trip
+        (a_c, a, x_c, x, ranges_x, perm_x), (b_c, b, y_c, y, ranges_y, perm_y) = clusterize_device_many([(a, x), (b, y)], cluster_scale)
+    else:
+        [a_c, a], [x_c, x], [ranges_x], perm_x = clusterize(a, x, scale=cluster_scale, labels=labels_x)
+        [b_c, b], [y_c, y], [ranges_y], perm_y = clusterize(b, y, scale=cluster_scale, labels=labels_y)
 
     # Switch to the fine clouds once the blur radius drops below the voxel size.
     # N.B.: like the reference (``:593-597``) the search variable is named `eps`, so the temperature
@@ -512,7 +539,7 @@ def sinkhorn_multiscale(
 
     f_aa, g_bb, g_ab, f_ba = sinkhorn_loop(
         softmin, a_logs, b_logs, C_xxs, C_yys, C_xys, C_yxs, eps_list, rho,
-        jumps=jumps, cost=cost_routine, kernel_truncation=partial(kernel_truncation, verbose=verbose, eps_last=eps_list[-1]),
+        jumps=jumps, cost=cost_routine, kernel_truncation=_truncation(verbose, eps_list[-1]),
         truncate=truncate, extrapolate=extrapolate, debias=debias,
     )
 

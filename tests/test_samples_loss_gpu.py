@@ -528,3 +528,19 @@ def test_gradients_through_kernel_potentials_match_the_tensorized_backend(cuda, 
         res[backend] = [F.detach(), G.detach()] + list(torch.autograd.grad(J, ts))
     for k, (got, want) in enumerate(zip(res["online"], res["tensorized"])):
         assert relerr(got.double().cpu().numpy(), want.cpu().numpy()) < 1e-4, ("F G dJ/da dJ/dx dJ/db dJ/dy".split()[k], name)
+
+
+def test_two_scale_loss_host_round_trips(cuda, monkeypatch):
+    """Host read-backs of one two-scale loss (round-4 review, N1: "<= 3 and listed"): the diameter (``max_diameter``, skipped when the
+    caller gives one), the cluster counts of BOTH clouds in one round trip, the keep-rule counts of the THREE truncations of the jump
+    in one — and, only with a gradient on a converged loop, the margin of the one-pass value + gradient."""
+    trips = []
+    orig = hip.read_back
+    monkeypatch.setattr(hip, "read_back", lambda *t: (trips.append(len(t)), orig(*t))[1])
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.rand(20_000, 3, generator=g).to(cuda), torch.rand(20_000, 3, generator=g).to(cuda)
+    L = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="multiscale")(x, y)
+    assert torch.isfinite(L)
+    assert trips == [2, 3], trips          # (clusters of x and y), (kept pairs of xy, xx, yy): two round trips with a given diameter
+    ref = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")(x, y)
+    assert abs(L.item() - ref.item()) < 0.2 * abs(ref.item())      # (sanity: the two-scale answer is the same loss up to its truncation)

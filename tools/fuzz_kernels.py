@@ -36,8 +36,11 @@ def main(n_cases=300, seed=0):
         ref = hip.softmin(eps, x, y, h, flags=hip.FLAG_DIRECT)
         diam2 = D * scale * scale
         tol = 4e-7 * diam2 + 2e-6 * ref.abs().max().item() + 1e-30
-        for name, flags in (("x32", 0), ("x32+prepack", hip.FLAG_PREPACK), ("x32 nosplit", hip.FLAG_NO_SPLIT),
-                            ("xdl16", hip.FLAG_XDL16), ("f32 mfma", hip.FLAG_F32_MFMA)):
+        variants = [("x32", 0), ("x32+prepack", hip.FLAG_PREPACK), ("x32 nosplit", hip.FLAG_NO_SPLIT),
+                    ("xdl16", hip.FLAG_XDL16), ("f32 mfma", hip.FLAG_F32_MFMA)]
+        if diam2 / eps < 1e5:      # the f16 x 2 exponent layout inside the range its flag vouches for (include/glhip.h)
+            variants += [("f16x2", hip.FLAG_F16X2), ("f16x2+prepack", hip.FLAG_F16X2 | hip.FLAG_PREPACK), ("f16x2 nosplit", hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT)]
+        for name, flags in variants:
             out = hip.softmin(eps, x, y, h, flags=flags)
             err = (out - ref).abs().max().item() / tol
             if not np.isfinite(err) and torch.equal(torch.isinf(out), torch.isinf(ref)):
