@@ -38,7 +38,9 @@ leg trace_all - 900 bash tools/trace_all.sh                             # per-co
 leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_report.py
 leg fuzz gpurun_out/fuzz.txt 200 python tools/fuzz_kernels.py 600 3
 leg small_probe gpurun_out/small_probe.txt 200 python tools/small_probe.py
-leg probe_batch gpurun_out/probe_batch.txt 100 python tools/probe_batch.py
+leg probe_shards gpurun_out/probe_shards.txt 200 python tools/probe_shards.py --calls 200
+leg probe_f16x2 gpurun_out/probe_f16x2.txt 400 python tools/probe_f16x2.py --dims 3,4,8,12,16
+leg probe_dist_xd gpurun_out/probe_dist_xd.txt 300 python tools/probe_dist_xd.py
 leg first_call gpurun_out/first_call.txt 100 python tools/first_call.py
 leg reference_protocol gpurun_out/reference_protocol.log 500 python tools/reference_protocol_bench.py --quick
 cat $STATUS

@@ -11,6 +11,7 @@ g = torch.randn(1, n, device=dev); v = torch.rand(1, n, device=dev) / n
 out = hip.softmin_fwd_raw(x, y, h, eps, 2)
 for _ in range(2):
     hip.softmin_fwd_raw(x, y, h, eps, 2)
+    hip.softmin_fwd_raw(x, y, h, eps, 2, flags=hip.FLAG_F16X2)      # the headline launch of round 5 (xd_fwd_kernel<D = 3, f16 x 2>)
     hip.softmin_bwd_x_raw(x, y, h, out, g, eps, 2)
     hip.kernel_conv_fwd_raw(hip.GAUSSIAN, x, y, v, 0.05)
     hip.kernel_conv_bwd_x_raw(hip.GAUSSIAN, x, y, v, g, 0.05)
