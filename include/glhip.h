@@ -127,6 +127,12 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges);
  * Same function as softmin_tensorized :32-71 on C = cost_routines[p](x, y) :26-29.
  *
  *   x (B,N,D)  y (B,M,D)  h (B,M) fp32  out (B,N) fp32
+ *
+ * Kernels by (p, D): p = 2 on the matrix cores for D <= 16 (glhip_softmin_x32.h / _xd.h; GLHIP_FLAG_F16X2 selects the two-piece f16
+ * layout); p = 1 on the matrix cores for block-sparse launches of D <= 3 with GLHIP_FLAG_MFMA_DIST (glhip_dist_x32.h) and, since
+ * round 5, for every DENSE launch of 4 <= D <= 16 (glhip_dist_xd.h: squared distances from the MFMA chain, pairs closer than 1/16 of
+ * their offset from the cloud's centre re-evaluated exactly); everything else (D > 16, block-sparse p = 1 in D > 3, GLHIP_FLAG_NO_MFMA /
+ * GLHIP_FLAG_DIRECT) on explicit differences.
  */
 int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
                       int B, int N, int M, int D, float eps, int p, int in_dtype,
@@ -135,7 +141,8 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
                       void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
- * One fused half-step of the symmetric Sinkhorn iteration (D <= 3):
+ * One fused half-step of the symmetric Sinkhorn iteration (every kernel of D <= 3; p = 2 for D <= 16; p = 1 on dense launches for
+ * D <= 16; GLHIP_EUNSUPPORTED elsewhere — compose glhip_softmin_fwd):
  *   t_i   = soft-min(eps, C(x,y), logw + pot / eps)_i          (pot == NULL: logw alone, the initialisation)
  *   out_i = damping * t_i                                       (prev == NULL)
  *   out_i = (prev_i + damping * t_i) / 2                        (prev != NULL; out must not alias prev)
@@ -209,6 +216,8 @@ int glhip_softmin_bwd_x(const void* x, const void* y, const float* h,
  *   The transposed product K^T @ a (:135-137) is the same call with x and y swapped.
  *
  *   v (B,M) fp32, out (B,N) fp32.
+ *   gaussian: matrix cores for D <= 16; laplacian / energy: matrix-core distances for block-sparse D <= 3 launches with
+ *   GLHIP_FLAG_MFMA_DIST and for dense launches of 4 <= D <= 16 (glhip_dist_xd.h, round 5); explicit differences elsewhere.
  */
 int glhip_kernel_conv_fwd(int kind, const void* x, const void* y, const float* v, float* out,
                           int B, int N, int M, int D, float blur, int in_dtype,
@@ -352,8 +361,8 @@ int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols
  * with dtype = float64; kernel_online, kernel_samples.py:128-137).  These entry points are that path: every array — clouds, dual
  * vector / weights, gradients, outputs — is `double`; same argument meaning, ranges convention and semantics (clamp of
  * utils.py:61, zero direction at clamped pairs) as glhip_softmin_fwd / glhip_softmin_bwd_x / glhip_kernel_conv_fwd /
- * glhip_kernel_conv_bwd_x above; 1 <= D <= 16 (GLHIP_EUNSUPPORTED beyond); no workspace, no flags.  One thread per row,
- * explicit differences, no matrix cores: ~4e11 pairs/s, for callers who need the digits.  The fused entry points (half-step,
+ * glhip_kernel_conv_bwd_x above; any D up to 4095 (D > 16 since round 5: run-time coordinate loops, slower); no workspace, no flags.
+ * One thread per row, explicit differences, no matrix cores: ~3-4e11 pairs/s, for callers who need the digits.  The fused entry points (half-step,
  * iteration, value + gradient) have no float64 form: compose these. */
 int glhip_softmin_fwd_f64(const double* x, const double* y, const double* h, double* out, int B, int N, int M, int D, double eps, int p,
                           const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* stream);
