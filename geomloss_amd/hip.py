@@ -723,7 +723,7 @@ def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0)
     B = xb.shape[0]
     al = _f32(a_log).reshape(B, -1)
     old = None if pots is None else tuple(_f32(t).reshape(B, -1) for t in pots)
-    new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & FLAG_NO_SPLIT))
+    new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2)))
     shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)
     return tuple(t.view(sh) for t, sh in zip(new, shapes))
 
@@ -745,7 +745,7 @@ class Iter4Plan:
         self.a_log = _f32(a_log).reshape(B, -1)
         self.dims = (B, N, M, D)
         self.debias = debias
-        self.flags = int(flags) | (ENV_FLAGS & FLAG_NO_SPLIT)
+        self.flags = int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2))
         self.shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)[: 4 if debias else 2]
         sizes = (N, M, N, M)[: 4 if debias else 2]
         dev = xb.device

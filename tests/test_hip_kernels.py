@@ -46,7 +46,8 @@ def test_softmin_fwd_vs_oracle(cuda, N, M, D, p, eps):
     # every code path of the forward kernel: matrix-core / VALU exponents, with / without column splits
     for flags in (0, hip.FLAG_F32_MFMA, hip.FLAG_XDL16, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_F32_MFMA | hip.FLAG_NO_SPLIT,
                   hip.FLAG_XDL16 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK,
-                  hip.FLAG_PREPACK | hip.FLAG_NO_SPLIT):
+                  hip.FLAG_PREPACK | hip.FLAG_NO_SPLIT, hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT, hip.FLAG_F16X2 | hip.FLAG_PREPACK):
+        # (GLHIP_FLAG_F16X2: the two-piece f16 layout of the p = 2 exponents — one MFMA per block; in range here; ignored for p = 1)
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags  # diam^2 <= D on the unit cube
     out_d = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, flags=hip.FLAG_DIRECT).cpu().numpy()
@@ -59,7 +60,7 @@ def test_softmin_fwd_many_columns(cuda, N, M, D):
     eps = 0.05**2
     x, y, h = _clouds(N + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, 2)
-    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK):
+    for flags in (0, hip.FLAG_XDL16, hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_PREPACK):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max(), flags
     # sorted clouds, batched, through the fused half-step entry point
@@ -160,7 +161,8 @@ def test_softmin_block_sparse_vs_oracle(cuda, p):
     empty = slice(ri[0, 0], ri[0, 1])
     live = np.ones(N, bool)
     live[empty] = False
-    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_XDL16):
+    for flags in (0, 8, hip.FLAG_NO_MFMA, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA | hip.FLAG_NO_SPLIT, hip.FLAG_PREPACK, hip.FLAG_XDL16,
+                  hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_PREPACK, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=p, ranges=rg, flags=flags).cpu().numpy()
         assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()   # LSE over the empty set
         assert np.abs(out[live] - ref[live]).max() < 1.2e-6 + 2e-6 * np.abs(ref[live]).max()
@@ -492,9 +494,10 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
                           rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("fl", [0, hip.FLAG_F16X2], ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (130, 2100, 2, None), (257, 255, 1, 3), (3000, 40, 3, None)])
 @pytest.mark.parametrize("debias", [True, False])
-def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias):
+def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl):
     """glhip_sinkhorn_iter4 (one launch per Sinkhorn iteration) == the simultaneous glhip_sinkhorn_step calls it replaces,
     for the initialisation and for an averaged update, with and without the two debiasing reductions."""
     x, y, _ = _clouds(90 + N, N, M, D, B=B)
@@ -504,9 +507,9 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias):
     b_log = np.log(rng.random(sh(M)) + 0.1).astype(np.float32)
     eps, damping = 0.02, 0.9
     xt, yt, al, bl = _t(x, cuda), _t(y, cuda), _t(a_log, cuda), _t(b_log, cuda)
-    step = lambda rows, cols, lw, pot, prev: hip.sinkhorn_step(eps, rows, cols, lw, pot, prev, damping)  # noqa: E731
+    step = lambda rows, cols, lw, pot, prev: hip.sinkhorn_step(eps, rows, cols, lw, pot, prev, damping, flags=fl)  # noqa: E731
 
-    init = hip.sinkhorn_iter4(eps, xt, yt, al, bl, None, damping, debias)
+    init = hip.sinkhorn_iter4(eps, xt, yt, al, bl, None, damping, debias, flags=fl)
     want = [step(xt, yt, bl, None, None), step(yt, xt, al, None, None)]
     if debias:
         want += [step(xt, xt, al, None, None), step(yt, yt, bl, None, None)]
@@ -519,7 +522,7 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias):
     f_ba, g_ab = want[0] + 0.01, want[1] - 0.02          # any old potentials
     f_aa, g_bb = (want[2] * 0.5, want[3] * 0.7) if debias else (None, None)
     old = (f_ba, g_ab, f_aa, g_bb) if debias else (f_ba, g_ab)
-    new = hip.sinkhorn_iter4(eps, xt, yt, al, bl, old, damping, debias)
+    new = hip.sinkhorn_iter4(eps, xt, yt, al, bl, old, damping, debias, flags=fl)
     want2 = [step(xt, yt, bl, g_ab, f_ba), step(yt, xt, al, f_ba, g_ab)]
     if debias:
         want2 += [step(xt, xt, al, f_aa, f_aa), step(yt, yt, bl, g_bb, g_bb)]

@@ -45,7 +45,8 @@ def _tol(ref, D):
 def test_softmin_fwd_vs_oracle(cuda, D, N, M, eps):
     x, y, h = _clouds(N + M + D, N, M, D)
     ref = oracle_c.softmin(eps, x, y, h, 2)
-    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):          # matrix cores with / without column splits; the VALU fallback
+    # matrix cores with / without column splits, on both K layouts (f16 x 2: in range here, diameter^2 / eps <= 6400); the VALU fallback
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), p=2, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < _tol(ref, D), flags
 
@@ -63,6 +64,8 @@ def test_softmin_fwd_large_launch_paths(cuda, D, N, M):
     assert np.abs(out[rows] - ref).max() < _tol(ref, D)
     alt = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=hip.FLAG_NO_SPLIT).cpu().numpy()
     assert np.abs(out - alt).max() < 2 * _tol(ref, D)             # every row, against the unsplit launch
+    h2 = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=hip.FLAG_F16X2).cpu().numpy()      # the f16 x 2 layout on the same paths
+    assert np.abs(h2[rows] - ref).max() < _tol(ref, D) and np.abs(h2 - out).max() < 2 * _tol(ref, D)
 
 
 @pytest.mark.parametrize("D,N,M", [(4, 33_000, 70_001), (8, 34_000, 66_000), (13, 33_333, 65_537), (16, 33_000, 70_001)])
@@ -95,6 +98,11 @@ def test_prepacked_columns_and_lds_dma_path(cuda, D, N, M):
     refk = o64.kconv("gaussian", x, y, v.cpu().numpy(), blur, rows=rows, device=cuda)
     outk = hip.kernel_conv("gaussian", xt, yt, v, blur)
     assert relerr(outk[sel].cpu().numpy(), refk) < 1e-4
+    # ... and the same three launches on the f16 x 2 layout (half the record bytes: other tile sizes, other split counts)
+    H2 = hip.FLAG_F16X2
+    assert np.abs(hip.softmin(eps, xt, yt, ht, flags=H2)[sel].cpu().numpy() - ref).max() < _tol(ref, D)
+    assert (hip.sinkhorn_step(eps, xt, yt, ht, pot, prev, 0.8, flags=H2) - unfused).abs().max().item() < 2 * _tol(ref, D)
+    assert relerr(hip.kernel_conv("gaussian", xt, yt, v, blur, flags=H2)[sel].cpu().numpy(), refk) < 1e-4
 
 
 def test_softmin_batched_bf16_and_fused_step(cuda):
@@ -145,19 +153,23 @@ def test_softmin_lazy_max_and_infinities(cuda, D):
     h[6] = -100000.0
     eps = 0.05**2
     ref = oracle_c.softmin(eps, x, y, h, 2)
-    for flags in (0, hip.FLAG_NO_SPLIT):
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), flags=flags).cpu().numpy()
-        assert np.isfinite(out).all() and np.abs(out - ref).max() < _tol(ref, D)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() < _tol(ref, D), flags
     h2 = (np.arange(M) // 64 * 48.0).astype(np.float32)
     h2[M // 2:] -= 3000.0
     h2[-3] = 5000.0
     ref2 = oracle_c.softmin(eps, x, y, h2, 2)
-    out2 = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h2, cuda)).cpu().numpy()
-    assert np.isfinite(out2).all() and relerr(out2, ref2) < 2e-6
+    for flags in (0, hip.FLAG_F16X2):
+        out2 = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h2, cuda), flags=flags).cpu().numpy()
+        assert np.isfinite(out2).all() and relerr(out2, ref2) < 2e-6, flags
     # a measure without any mass: the reference returns +inf; every kernel of the library (D <= 3 included) returns a huge finite
     # potential instead — the neutral padding columns of the last tile carry -1e30, not -inf, and are all that is left
     allinf = hip.softmin(eps, _t(x, cuda), _t(y, cuda), torch.full((M,), -math.inf, device=cuda)).cpu().numpy()
     assert (allinf > 1e20).all()
+    # (the f16 x 2 layout floors every exponent at -5e5 and recognises a row that never left the floor: +inf, like the reference)
+    allinf = hip.softmin(eps, _t(x, cuda), _t(y, cuda), torch.full((M,), -math.inf, device=cuda), flags=hip.FLAG_F16X2).cpu().numpy()
+    assert np.isposinf(allinf).all()
 
 
 def _random_ranges(rng, N, M, ci, cj, density, dev):
@@ -185,15 +197,16 @@ def test_block_sparse_softmin_and_gaussian(cuda, D, ci, cj):
     empty = slice(ri[0, 0], ri[0, 1])
     live = np.ones(N, bool)
     live[empty] = False
-    for flags in (0, hip.FLAG_NO_SPLIT):
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT):
         out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(h, cuda), ranges=rg, flags=flags).cpu().numpy()
-        assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all()
-        assert np.abs(out[live] - ref[live]).max() < _tol(ref[live], D)
+        assert np.isposinf(out[empty]).all() and np.isposinf(ref[empty]).all(), flags
+        assert np.abs(out[live] - ref[live]).max() < _tol(ref[live], D), flags
     v = (np.abs(h) / M).astype(np.float32)
     blur = 0.3
     refk = oracle_c.kconv("gaussian", x, y, v, blur, ranges=tup)
-    k = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg).cpu().numpy()
-    assert (k[empty] == 0).all() and relerr(k, refk) < 1e-4
+    for flags in (0, hip.FLAG_F16X2):
+        k = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, ranges=rg, flags=flags).cpu().numpy()
+        assert (k[empty] == 0).all() and relerr(k, refk) < 1e-4, flags
 
 
 @pytest.mark.parametrize("D", [4, 6, 11, 16])
@@ -207,7 +220,7 @@ def test_gaussian_product_vs_oracle(cuda, D, N, M, B):
     ref = one(x, y, v) if B is None else np.stack([one(x[b], y[b], v[b]) for b in range(B)])
     bound = one(x, y, np.abs(v)) if B is None else np.stack([one(x[b], y[b], np.abs(v[b])) for b in range(B)])
     tol = 3e-6 * np.abs(ref).max() + 2.4e-7 * D / blur**2 * np.abs(bound).max()     # as in test_hip_kernels.py
-    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_F16X2, hip.FLAG_NO_MFMA):
         out = hip.kernel_conv("gaussian", _t(x, cuda), _t(y, cuda), _t(v, cuda), blur, flags=flags).cpu().numpy()
         assert np.abs(out - ref).max() < tol, flags
 
@@ -256,14 +269,17 @@ def test_multiscale_4d_with_user_labels(cuda):
 
 # ---- gradients on the transposed 32x32x16 kernel (csrc/glhip_wsum_t32.h): 4 <= D <= 16 -----
 
-T32_CASES = [(4, 0), (5, 0), (8, 0), (9, 0), (16, 0)]
+# (dimension, flags): the default bf16 x 3 layout, and the f16 x 2 one — on which D >= 7 soft-min gradients (and value + gradient) run
+# wsum_t32q_kernel, their weighted sums on the matrix cores too (round 5)
+T32_CASES = [(4, 0), (5, 0), (8, 0), (9, 0), (16, 0), (5, hip.FLAG_F16X2), (7, hip.FLAG_F16X2), (8, hip.FLAG_F16X2), (12, hip.FLAG_F16X2),
+             (16, hip.FLAG_F16X2)]
 
 
 @pytest.mark.parametrize("D,flags", T32_CASES)
 @pytest.mark.parametrize("N,M,B", [(300, 257, None), (1030, 2100, None), (257, 300, 3), (700, 70_001, None)])
 def test_softmin_gradient_transposed_kernel(cuda, D, flags, N, M, B):
     if M > 50_000 and D not in (4, 16):
-        pytest.skip("the many-column launch is exercised for three dimensions")
+        pytest.skip("the many-column launch is exercised for two dimensions")
     x, y, h = _clouds(N + D, N, M, D, B=B)
     g = np.random.default_rng(6).standard_normal(x.shape[:-1]).astype(np.float32)
     eps = 0.1 * D / 3 if M < 50_000 else 0.05**2 * D
@@ -323,7 +339,7 @@ def test_gaussian_gradient_and_one_pass_transposed_kernel(cuda, D, flags, N, M, 
         assert relerr((gb.unsqueeze(-1) * unit).reshape(shp + (D,)).cpu().numpy(), refg) < 1e-4, fl
 
 
-@pytest.mark.parametrize("D,flags", [(4, 0), (9, 0)])
+@pytest.mark.parametrize("D,flags", [(4, 0), (9, 0), (5, hip.FLAG_F16X2), (9, hip.FLAG_F16X2), (16, hip.FLAG_F16X2)])
 def test_block_sparse_gradients_transposed_kernel(cuda, D, flags):
     rng = np.random.default_rng(19)
     N, M = 2300, 2600
