@@ -68,6 +68,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """Rank 0 prints ONE JSON line on stdout — but libraries write there too (RCCL prints a five-line version banner on fd 1 when the
+    process group goes away).  Keep a private copy of the real stdout for the line and point fd 1 at stderr for everybody else."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def make_problem(n, dev, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.rand(n, 3, generator=g).to(dev)
@@ -103,13 +122,17 @@ def cpu_baseline(budget_s=10.0):
     g = torch.Generator().manual_seed(0)
     x5, y5 = torch.rand(1, 5000, 3, generator=g), torch.rand(1, 5000, 3, generator=g)
     # PyTorch's CPU ops do not scale to every core of a many-socket host: pick the fastest thread count from a sweep
-    best_t, best_threads = None, 1
+    # (on the first 1000 points of the clouds: over-subscribed, 256 threads take 34 s for ONE loss at N = 2000 — 600x the 16-thread time)
+    best_t, best_threads, sweep = None, 1, {}
+    xs, ys = x1[:, :1000].contiguous(), y1[:, :1000].contiguous()
     for threads in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)}):
         torch.set_num_threads(threads)
         sinkhorn_tensorized_cpu(x1[:, :300], y1[:, :300])   # warm the pool
+        cnt = {}
         t0 = time.perf_counter()
-        sinkhorn_tensorized_cpu(x1, y1)
+        sinkhorn_tensorized_cpu(xs, ys, count=cnt)
         dt = time.perf_counter() - t0
+        sweep[threads] = (cnt["softmin_calls"] * 1000.0 * 1000.0 / dt, dt)
         if best_t is None or dt < best_t:
             best_t, best_threads = dt, threads
     torch.set_num_threads(best_threads)
@@ -125,16 +148,13 @@ def cpu_baseline(budget_s=10.0):
 
     v1, t1, n1, c1, l1 = timed(x1, y1, 9, budget_s * 0.5)
     v5, t5, n5, c5, _ = timed(x5, y5, 3, budget_s * 0.5)
-    all_cores = None
-    if best_threads != cores:      # north star: "core count stated" — every logical core as well.  PyTorch's CPU ops thrash when
-        # over-subscribed (256 threads on this class of host: 600x slower than 16, 34 s for one loss at N = 2000), so the all-cores
-        # leg runs ONE loss on the first 1000 points of the same clouds: same 36 soft-mins, a quarter of the pairs
-        torch.set_num_threads(cores)
-        va, ta, na, _, _ = timed(x1[:, :1000], y1[:, :1000], 1, 1.0)
-        all_cores = {"value": va, "unit": "pairs/s", "cores": cores, "seconds": ta, "runs": na, "sample": "N = M = 1000 (first half of the clouds), one run"}
-        torch.set_num_threads(best_threads)
+    # north star: "core count stated" — every logical core as well: the sweep's entry for `cores` threads (same 36 soft-mins, N = M = 1000)
+    all_cores = {"value": sweep[cores][0], "unit": "pairs/s", "cores": cores, "seconds": sweep[cores][1], "runs": 1,
+                 "sample": "N = M = 1000 (first half of the clouds of BASELINE configs[0]), one run"}
+    thread_sweep = {str(k): v[0] for k, v in sorted(sweep.items())}
     return {
-        "value": v1, "unit": "pairs/s", "cores": best_threads, "cores_total": cores, "all_cores": all_cores, "kind": "port",
+        "value": v1, "unit": "pairs/s", "cores": best_threads, "cores_total": cores, "all_cores": all_cores, "thread_sweep_pairs_per_s_n1000": thread_sweep,
+        "kind": "port",
         "sample": f"BASELINE configs[0] exactly: PyTorch-CPU tensorized SamplesLoss('sinkhorn',p=2,blur=.05) forward, N=M=2000 2D fp32, "
                   f"seed 0 ({c1} dense soft-mins, median of {n1} runs, {t1:.3f} s each, loss {l1:.7e}; reference value 1.9925134e-04); "
                   f"{best_threads} torch threads = fastest of a sweep on a host with {cores} logical cores. "
@@ -471,7 +491,7 @@ def run_headline(args, dev):
                 res[key] = {"error": repr(e)}
                 if key == "cpu_baseline":
                     res[key].update(value=None, unit="pairs/s", cores=os.cpu_count(), kind="port", sample="failed")
-    print(json.dumps(res), flush=True)
+    emit(res)
 
 
 def run_sharded(args, dev, rank, world):
@@ -526,7 +546,7 @@ def run_sharded(args, dev, rank, world):
     dist.all_gather_object(per_rank, {"rank": rank, "problems": hi - lo, "local_loss_ms": round(local_ms, 4), "allreduce_ms": round(allreduce_ms, 4)})
     if rank == 0:
         pairs = cfg4_pairs(B)
-        print(json.dumps({
+        emit(({
             "metric": "softmin pairs/s of the batch-sharded Sinkhorn loss (BASELINE configs[3]: B=256, N=M=4096 3D bf16)",
             "value": pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "ranks_seen": dist.get_world_size(),
             "backend": dist.get_backend(), "devices": sorted(set(devs)), "steps": args.steps, "warmup": args.warmup,
@@ -551,7 +571,7 @@ def run_sharded(args, dev, rank, world):
                         "allreduce_ms = waiting on the slowest rank + the barrier of the protocol",
                 "problems_per_rank": [r["problems"] for r in sorted(per_rank, key=lambda r: r["rank"])],
             },
-        }), flush=True)
+        }))
 
 
 def self_launch(args):
@@ -592,10 +612,10 @@ def run_dry(args, rank, world):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"metric": "dry run of the batch-sharded leg (no kernels timed)", "value": None, "unit": "pairs/s",
+        emit(({"metric": "dry run of the batch-sharded leg (no kernels timed)", "value": None, "unit": "pairs/s",
                           "n_gpus": world, "ranks_seen": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": t.item() / args.steps * 1e3, "dry_run": True, "backend": "gloo",
-                          "items_all_ranks": float(total)}), flush=True)
+                          "items_all_ranks": float(total)}))
 
 
 def main():
@@ -622,6 +642,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))      # not under torchrun: start the ranks ourselves
+    claim_stdout()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
