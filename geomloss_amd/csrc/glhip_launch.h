@@ -708,6 +708,34 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
         hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
 }
 
+// the same for 4 <= D <= 16: the multi launch of the xd kernel (glhip_softmin_xd.h), columns packed on the fly, 4 wavefronts x 1 row tile
+template <int D, typename T, int L>
+void launch_iter4_xd(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;
+    constexpr int NW = 4, kRows = NW * 32;
+    int maxN = 0, minM = m.M[0];
+    long row_blocks = 0;
+    for (int k = 0; k < m.count; ++k) {
+        maxN = m.N[k] > maxN ? m.N[k] : maxN;
+        minM = m.M[k] < minM ? m.M[k] : minM;
+        row_blocks += (long)B * ((m.N[k] + kRows - 1) / kRows);
+        m.pk[k] = PackedCols{nullptr, 0};
+    }
+    const long per_split = (long)m.count * B * maxN * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = 0;   // per problem, set in the kernels
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    m.ws_stride = (long)sp.n_splits * B * maxN * 2;
+    const int gx = (maxN + kRows - 1) / kRows;
+    hipLaunchKernelGGL((xd_fwd_multi_kernel<D, T, NW, L>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, m, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
+}
+
 template <typename T>
 int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
                 const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
@@ -726,6 +754,14 @@ int iter4_typed(const void* x, const void* y, const float* a_log, const float* b
         m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
     } else {
         m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+    }
+    if (D > 3) {      // 4 <= D <= 16 (round 5)
+#define GL_XD(DD) \
+    if (sc.h2) launch_iter4_xd<DD, T, XL_F16X2>(m, B, sc, st); \
+    else launch_iter4_xd<DD, T, XL_BF16X3>(m, B, sc, st)
+        GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+        return GLHIP_OK;
     }
     if (sc.h2) {      // GLHIP_FLAG_F16X2: the iteration on the f16 x 2 layout, like the half-steps it replaces
         if (D == 1) launch_iter4<1, T, XL_F16X2>(m, B, sc, st);

@@ -132,9 +132,21 @@ __device__ __forceinline__ float xd_weighted_sum(const f32x16& u, const float* _
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE, int L = XL_BF16X3>
-__global__ void __launch_bounds__(NW * 64)
-xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPacked pk) {
+// LDS of one workgroup: tile buffers (two with pre-packed columns) and, for the gaussian product, the weights of the tile
+template <int MODE, int D, bool PRE, int L>
+struct XdLds {
+    using S = XdShape<D, L>;
+    static constexpr int kTileD = PRE ? S::kTilePre : S::kTile;
+    static constexpr int kBufs = PRE ? 2 : 1;
+    static constexpr int kTileV = (kTileD + 63) & ~63;               // weights travel 64 at a time (one 4-byte LDS-DMA instruction)
+    static constexpr int kRecs = kBufs * kTileD * S::NBP;            // [buffer][column group of 32][K block 0..NBP-1][column]
+    static constexpr int kWeights = MODE == XD_GAUSS ? kBufs * kTileV : 4;
+};
+
+// The work of one workgroup: row block bx of batch item b, column split `split`.
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE, int L>
+__device__ __forceinline__ void xd_fwd_body(const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp, const XdPacked& pk,
+                                            int bx, int b, int split, uint4* tileBuf, float* tileVBuf) {
     using S = XdShape<D, L>;
     constexpr float kFloor = (L == XL_F16X2) ? kH2Floor : kMinusHuge;      // the running maximum of a row that has seen no mass yet
     static_assert(!(PRE && SPARSE), "pre-packed columns serve dense launches");
@@ -142,16 +154,11 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
     constexpr int kRowsPerWave = RT * 32;
     constexpr int kRowsPerBlock = NW * kRowsPerWave;
     constexpr int kThreads = NW * 64;
-    constexpr int kBufs = PRE ? 2 : 1;
-    __shared__ uint4 tileBuf[kBufs * kTileD * NBP];           // [buffer][column group of 32][K block 0..NBP-1][column]
-    constexpr int kTileV = (kTileD + 63) & ~63;               // weights travel 64 at a time (one 4-byte LDS-DMA instruction)
-    __shared__ __attribute__((aligned(16))) float tileVBuf[MODE == XD_GAUSS ? kBufs * kTileV : 4];    // gaussian: the weights v_j of the tile (read back as float4)
+    constexpr int kTileV = XdLds<MODE, D, PRE, L>::kTileV;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, b, split;
-    workgroup_coords(sp, bx, b, split);
     const int ns = sp.n_splits;
     const int half = lane >> 5;
     const int l31 = lane & 31;
@@ -370,6 +377,37 @@ xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPac
             }
         }
     }
+}
+
+template <int MODE, int D, typename T, bool SPARSE, int RT, int NW, bool PRE, int L = XL_BF16X3>
+__global__ void __launch_bounds__(NW * 64)
+xd_fwd_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, XdPacked pk) {
+    using LDS = XdLds<MODE, D, PRE, L>;
+    __shared__ uint4 tileBuf[LDS::kRecs];
+    __shared__ __attribute__((aligned(16))) float tileVBuf[LDS::kWeights];    // gaussian: the weights v_j of the tile (read back as float4)
+    int bx, b, split;
+    workgroup_coords(sp, bx, b, split);
+    xd_fwd_body<MODE, D, T, SPARSE, RT, NW, PRE, L>(prm, rg, N, M, sp, pk, bx, b, split, tileBuf, tileVBuf);
+}
+
+// Up to four independent dense soft-min reductions in ONE launch — the four updates of a Sinkhorn iteration (glhip_sinkhorn_iter4)
+// for clouds of dimension 4 <= D <= 16 (round 5): the multi launch of glhip_softmin_x32.h on this kernel's body; columns packed on the
+// fly.  grid = (max row blocks, B, n_splits * count); problem k = blockIdx.z / n_splits.
+template <int D, typename T, int NW, int L = XL_BF16X3>
+__global__ void __launch_bounds__(NW * 64)
+xd_fwd_multi_kernel(SoftminMulti<T> m, SplitInfo sp) {
+    using LDS = XdLds<XD_SOFTMIN, D, false, L>;
+    __shared__ uint4 tileBuf[LDS::kRecs];
+    __shared__ __attribute__((aligned(16))) float tileVBuf[LDS::kWeights];
+    const int k = blockIdx.z / sp.n_splits;
+    const int split = blockIdx.z - k * sp.n_splits;
+    const int N = m.N[k], M = m.M[k];
+    if ((int)blockIdx.x * (NW * 32) >= N) return;
+    SplitInfo spk = sp;
+    spk.workspace += k * m.ws_stride;
+    spk.split_stride = (long)gridDim.y * N * 2;   // this problem's own row count
+    xd_fwd_body<XD_SOFTMIN, D, T, false, 1, NW, false, L>(m.p[k], Ranges{nullptr, nullptr, nullptr, nullptr}, N, M, spk, XdPacked{nullptr, 0},
+                                                          (int)blockIdx.x, (int)blockIdx.y, split, tileBuf, tileVBuf);
 }
 
 }  // namespace glhip

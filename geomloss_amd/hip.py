@@ -713,7 +713,7 @@ def softmin_value_and_grad(eps, x, y, h, guess, margin, ranges=None, flags=0):
 
 
 def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0):
-    """One whole iteration of the symmetric Sinkhorn loop on the GPU, non-differentiable (dense, p = 2, D <= 3).
+    """One whole iteration of the symmetric Sinkhorn loop on the GPU, non-differentiable (dense, p = 2, D <= 16).
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); a_log: (N,)|(1,N)|(B,N), b_log likewise; ``pots`` None (initial potentials)
     or the old ``(f_ba, g_ab, f_aa, g_bb)`` / ``(f_ba, g_ab)``.  Returns the new potentials, shaped like a_log / b_log."""
@@ -801,7 +801,7 @@ class _Last4(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, plan, eps, damping, *pots):
         outs = plan.run(eps, damping, tuple(p.detach() for p in pots), last=True)
-        ctx.plan, ctx.cfg = plan, (eps, damping, x.shape, x.dtype, y.shape, y.dtype)
+        ctx.plan, ctx.cfg, ctx.extra_flags = plan, (eps, damping, x.shape, x.dtype, y.shape, y.dtype), plan.extra_flags
         ctx.save_for_backward(*pots, *outs)
         return outs
 
@@ -826,7 +826,7 @@ class _Last4(torch.autograd.Function):
             h = logw + pot.reshape(B, -1) * (1.0 / eps)
             out = outs[i].reshape(B, -1) * (1.0 / damping)            # the soft-min value itself
             gr = softmin_bwd_x_raw(rows, cols, h, out.contiguous(), (g.reshape(B, -1).float() * damping).contiguous(), eps, 2, None,
-                                   plan.flags)
+                                   plan.flags | ctx.extra_flags)
             if i % 2 == 0:
                 gx = gr if gx is None else gx + gr
             else:

@@ -143,7 +143,7 @@ def sinkhorn_loop(*, cost, log_a, log_b, descent, debias=True, last_extrapolatio
         f_aa, g_bb = (init(x, x, a, a), init(y, y, b, b)) if debias else (None, None)
 
         plan, before = None, None
-        fusable = (x.shape[1] <= 3 and float(x.shape[0]) * y.shape[0] < 4e9
+        fusable = (x.shape[1] <= hip.XD_MAX_DIM and float(x.shape[0]) * y.shape[0] < 4e9
                    and not (hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16)))   # default kernel only
         if fusable:   # one launch per iteration (glhip_sinkhorn_iter4)
             plan = hip.Iter4Plan(x, y, log_a, log_b, debias)

@@ -180,11 +180,11 @@ class _HipSoftmin:
 
     def _iter4_plan(self, C_xy, a_log, b_log, debias, create):
         """The hip.Iter4Plan of the loop being run, (re)built when the inputs change; None when the one-launch-per-iteration
-        path does not apply: block-sparse levels, p = 1, D > 3, and problems big enough for every soft-min to fill the GPU
+        path does not apply: block-sparse levels, p = 1, D > 16, and problems big enough for every soft-min to fill the GPU
         on its own (those run faster as separate launches with pre-packed columns).  The coarse level of the multiscale
         backend (dense, ~2e3 clusters with their own weights) qualifies: its 7 x 4 soft-mins become 7 launches."""
         x, y = C_xy[0], C_xy[1]
-        if self.p != 2 or x.shape[-1] > 3 or not _fuse_iterations or x.dtype == torch.float64:
+        if self.p != 2 or x.shape[-1] > hip.XD_MAX_DIM or not _fuse_iterations or x.dtype == torch.float64:
             return None
         if hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16):
             return None     # the one-launch iteration exists on the default kernel only: a kernel-selection flag means "not that one"

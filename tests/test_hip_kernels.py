@@ -495,7 +495,8 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
 
 
 @pytest.mark.parametrize("fl", [0, hip.FLAG_F16X2], ids=["bf16x3", "f16x2"])
-@pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (130, 2100, 2, None), (257, 255, 1, 3), (3000, 40, 3, None)])
+@pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (130, 2100, 2, None), (257, 255, 1, 3), (3000, 40, 3, None),
+                                     (600, 700, 5, None), (257, 255, 9, 3), (300, 1100, 16, None)])      # D > 3: the xd kernel's multi launch (round 5)
 @pytest.mark.parametrize("debias", [True, False])
 def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl):
     """glhip_sinkhorn_iter4 (one launch per Sinkhorn iteration) == the simultaneous glhip_sinkhorn_step calls it replaces,
