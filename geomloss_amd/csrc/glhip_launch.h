@@ -516,6 +516,28 @@ void launch_dist_xd(const DistParams<T>& prm, const typename MergeOp::Params& mp
         hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, mprm, none, N, sp);
 }
 
+// ... and their gradients with respect to the row points (dist_xd_grad_kernel)
+template <int MODE, int D, typename T, class MergeOp>
+void launch_dist_xd_grad(const DistXdGradParams<T>& gp, const typename MergeOp::Params& mprm, int B, int N, int M, const Scratch& sc,
+                         hipStream_t st) {
+    constexpr int NW = 8, kRows = NW * 32;
+    constexpr int kPart = MODE == DM_SOFTMIN_P1 ? D + 1 : D;
+    static_assert(MergeOp::kPartial == kPart && MergeOp::kRows == 1, "partial formats differ");
+    const int gx = (N + kRows - 1) / kRows;
+    const long per_split = (long)B * N * kPart * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits((long)gx * B, M, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = (long)B * N * kPart;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    const Ranges none{nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((dist_xd_grad_kernel<MODE, D, T, NW>), dim3(gx, B, sp.n_splits), dim3(NW * 64), 0, st, gp, N, M, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_kernel<MergeOp, false>), dim3((N + kBlock - 1) / kBlock, B, 1), dim3(kBlock), 0, st, mprm, none, N, sp);
+}
+
 // weighted-sum reductions on transposed 32 x 32 blocks (glhip_wsum_t32.h), 1 <= D <= 16; splits / grids / merges as launch_wsum
 // WQ: the weighted sums on the matrix cores too (wsum_t32q_kernel: soft-min gradient, f16 x 2, one row tile per wavefront)
 template <int MODE, int D, typename T, class MergeOp, int RT, int L, bool WQ = false>
@@ -856,6 +878,17 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
                 return GLHIP_OK;
             }
         } else {
+            if (p == 1 && D <= kXdMaxD && n_ranges == 0 && !out && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // p = 1 gradient, dense
+                SoftminParams<T> mprm = make_softmin_params<T>(x, y, h, nullptr, eps, 1, nullptr, nullptr, 1.f, 0.f);
+                mprm.fwd = fwd; mprm.g = g; mprm.gx = gx;
+                DistXdGradParams<T> gp;
+                gp.d = DistParams<T>{mprm.x, mprm.y, h, nullptr, nullptr, nullptr, s2, 1e-8f * s2 * s2, out_scale, 0.f, 1.f, 0.f, dist_guard()};
+                gp.fwd = fwd; gp.g = g; gp.gx = gx; gp.gscale = 1.f;
+#define GL_XD(DD) launch_dist_xd_grad<DM_SOFTMIN_P1, DD, T, SoftminBwdOp<DD, 1, true, 1, T>>(gp, mprm, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
             if (p == 2 && D <= kXdMaxD && !(flags & (GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_DIRECT))) {   // gradient (+ value), 4 <= D <= 16
                 SoftminParams<T> prm = make_softmin_params<T>(x, y, h, out, eps, 2, nullptr, nullptr, 1.f, 0.f);
                 prm.fwd = fwd; prm.g = g; prm.gx = gx; prm.shift2 = step.shift2;
@@ -1038,6 +1071,22 @@ int conv_typed(int kind, const void* x, const void* y, const float* v, float* ou
                 return GLHIP_OK;
             }
         } else {
+            if (kind != GLHIP_GAUSSIAN && D <= kXdMaxD && n_ranges == 0 && !(flags & GLHIP_FLAG_NO_MFMA)) {   // laplacian / energy gradients, dense
+                const bool lap = kind == GLHIP_LAPLACIAN;
+                const float t = lap ? kLog2e / blur : 1.0f;
+                ConvParams<T> mprm;
+                mprm.x = static_cast<const T*>(x); mprm.y = static_cast<const T*>(y); mprm.v = v; mprm.out = nullptr; mprm.g = g; mprm.gx = gx;
+                mprm.t = t; mprm.gscale = lap ? -1.0f / blur : -1.0f; mprm.clamp2 = 1e-8f * (lap ? kLog2e * kLog2e : 1.f);
+                DistXdGradParams<T> gp;
+                gp.d = DistParams<T>{mprm.x, mprm.y, v, nullptr, nullptr, nullptr, t, mprm.clamp2, 1.f, 0.f, 1.f, 0.f, dist_guard()};
+                gp.fwd = nullptr; gp.g = g; gp.gx = gx; gp.gscale = mprm.gscale;
+#define GL_XD(DD) \
+    if (lap) launch_dist_xd_grad<DM_LAPLACIAN, DD, T, ConvOp<GLHIP_LAPLACIAN, DD, 1, T, 1>>(gp, mprm, B, N, M, sc, st); \
+    else launch_dist_xd_grad<DM_ENERGY, DD, T, ConvOp<GLHIP_ENERGY, DD, 1, T, 1>>(gp, mprm, B, N, M, sc, st)
+                GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+                return GLHIP_OK;
+            }
             if (kind == GLHIP_GAUSSIAN && D <= kXdMaxD && !(flags & GLHIP_FLAG_NO_MFMA)) {   // gaussian gradient, 4 <= D <= 16
                 ConvParams<T> prm;
                 prm.x = static_cast<const T*>(x); prm.y = static_cast<const T*>(y); prm.v = v; prm.out = out; prm.g = g; prm.gx = gx;

@@ -198,6 +198,7 @@ int glhip_lse_lines_bwd(const float* h, const float* lse, const float* grad_out,
  *   P_ij = exp( h_j - C_ij/eps + out_i/eps )   (rows of P sum to 1; we renormalise by the
  *   recomputed row sum, as autograd's logsumexp backward does).
  * Replaces: the symbolic KeOps `Grad` of the generic_logsumexp above.
+ * (p = 1, dense, 4 <= D <= 16: glhip_dist_xd.h since round 5 — distances from the MFMA chain, near pairs from the points themselves.)
  *   out = the saved forward result (B,N);  grad_out (B,N) fp32;  grad_x (B,N,D) fp32.
  */
 int glhip_softmin_bwd_x(const void* x, const void* y, const float* h,

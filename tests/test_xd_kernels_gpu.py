@@ -392,6 +392,21 @@ def test_distance_reductions_xd_vs_oracle(cuda, D, N, M, B):
         assert np.abs(f - ref_f).max() < tol * 2e-6 * max(1.0, np.abs(ref_f).max()), flags
         assert relerr(hip.kernel_conv("laplacian", xt, yt, vt, blur, flags=flags).cpu().numpy(), ref_l) < tol * 5e-6, flags
         assert relerr(hip.kernel_conv("energy", xt, yt, vt, blur, flags=flags).cpu().numpy(), ref_e) < tol * 5e-6, flags
+    # gradients with respect to the rows (dist_xd_grad_kernel; GLHIP_FLAG_NO_MFMA: the one-thread-per-row kernel), zero direction at
+    # coincident pairs like autograd through sqrt(clamp_min(d2, 1e-8))
+    g = np.random.default_rng(5).standard_normal(ref_f.shape).astype(np.float32)
+    hf = np.where(np.isinf(h), -40.0, h).astype(np.float32)          # finite dual values: every row keeps some mass
+    rg_f = np.stack([oracle_c.softmin_grad_x(eps, sel(x, b), sel(y, b), sel(hf, b), sel(g, b), 1) for b in bs]).reshape(x.shape)
+    rg_l = np.stack([oracle_c.kconv_grad_x("laplacian", sel(x, b), sel(y, b), sel(v, b), sel(g, b), blur) for b in bs]).reshape(x.shape)
+    rg_e = np.stack([oracle_c.kconv_grad_x("energy", sel(x, b), sel(y, b), sel(v, b), sel(g, b), blur) for b in bs]).reshape(x.shape)
+    for flags in (0, hip.FLAG_NO_SPLIT, hip.FLAG_NO_MFMA):
+        xg = xt.clone().requires_grad_(True)
+        (gx,) = torch.autograd.grad(hip.softmin(eps, xg, yt, _t(hf, cuda), p=1, flags=flags), [xg], grad_outputs=_t(g, cuda))
+        assert relerr(gx.cpu().numpy(), rg_f) < 3e-5, flags
+        for kind, want in (("laplacian", rg_l), ("energy", rg_e)):
+            xg = xt.clone().requires_grad_(True)
+            (gx,) = torch.autograd.grad(hip.kernel_conv(kind, xg, yt, vt, blur, flags=flags), [xg], grad_outputs=_t(g, cuda))
+            assert relerr(gx.cpu().numpy(), want) < 3e-5, (kind, flags)
     # fused half-step (dense p = 1: one launch)
     rng = np.random.default_rng(3)
     pot, prev = rng.standard_normal(h.shape).astype(np.float32) * 0.05, rng.standard_normal(ref_f.shape).astype(np.float32)
