@@ -127,7 +127,7 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
                          int in_dtype, int first, void* workspace, size_t workspace_bytes, int flags, void* stream) {
     int rc = check_common("glhip_sinkhorn_iter4", x, y, b_log, B, N, M, D, in_dtype, nullptr, nullptr, nullptr, 0);
     if (rc) return rc;
-    if (p != 2 || D > kXdMaxD) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_iter4: only p = 2, D <= 16 (got p = %d, D = %d)", p, D);
+    if ((p != 1 && p != 2) || D > kXdMaxD) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_iter4: only p = 1, 2 and D <= 16 (got p = %d, D = %d)", p, D);
     if (flags & (GLHIP_FLAG_DIRECT | GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_F32_MFMA | GLHIP_FLAG_XDL16))
         return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_iter4: runs on the default 32x32x16 kernel only (flags = %d)", flags);
     if (B == 0 || N == 0 || M == 0) return GLHIP_OK;
@@ -142,8 +142,8 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Scratch sc = make_scratch(workspace, workspace_bytes, flags & ~GLHIP_FLAG_PREPACK, 0, N);
     rc = (in_dtype == GLHIP_F32)
-             ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st)
-             : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, first, sc, st);
+             ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st)
+             : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st);
     return rc ? rc : check_launch("glhip_sinkhorn_iter4");
 }
 

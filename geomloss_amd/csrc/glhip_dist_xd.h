@@ -46,20 +46,20 @@ __device__ __forceinline__ float exact_d2(const T* __restrict__ x, const T* __re
     return fmaxf(e, clamp2);
 }
 
+// The work of one workgroup: row block bx of batch item b, column split `split`.
+//   tile  [kTile * NBP] records: [column group of 32][K block][column];   tileS [kTile]: S_j = log2(e) h_j (soft-min) | v_j (products)
 template <int MODE, int D, typename T, int NW>
-__global__ void __launch_bounds__(NW * 64, 4)
-dist_xd_kernel(DistParams<T> prm, int N, int M, SplitInfo sp) {
+__device__ __forceinline__ void dist_xd_body(const DistParams<T>& prm, int N, int M, const SplitInfo& sp, int bx, int b, int split,
+                                             uint4* tile, float* tileS) {
     using S = DistXdShape<D>;
     constexpr int NM = S::NM, NBP = S::NBP, kTileD = S::kTile;
     constexpr int kRowsPerBlock = NW * 32;
     constexpr int kThreads = NW * 64;
-    __shared__ uint4 tile[kTileD * NBP];                              // [column group of 32][K block][column]
-    __shared__ __attribute__((aligned(16))) float tileS[kTileD];      // S_j = log2(e) h_j (soft-min) | v_j (products)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, split = blockIdx.z, ns = sp.n_splits;
+    const int ns = sp.n_splits;
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int rec0 = half * 32 + l31;
@@ -70,7 +70,7 @@ dist_xd_kernel(DistParams<T> prm, int N, int M, SplitInfo sp) {
     float centre[D];
     launch_centre<D, T>(prm.x, b, N, centre);
 
-    const int row0 = blockIdx.x * kRowsPerBlock;
+    const int row0 = bx * kRowsPerBlock;
     const int wave_row0 = row0 + wave * 32;
     const bool wave_active = wave_row0 < N;
     const int i_lane = min(wave_row0 + l31, N - 1);
@@ -197,6 +197,41 @@ dist_xd_kernel(DistParams<T> prm, int N, int M, SplitInfo sp) {
             }
         }
     }
+}
+
+template <int MODE, int D, typename T, int NW>
+__global__ void __launch_bounds__(NW * 64, 4)
+dist_xd_kernel(DistParams<T> prm, int N, int M, SplitInfo sp) {
+    using S = DistXdShape<D>;
+    __shared__ uint4 tile[S::kTile * S::NBP];
+    __shared__ __attribute__((aligned(16))) float tileS[S::kTile];
+    dist_xd_body<MODE, D, T, NW>(prm, N, M, sp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, tile, tileS);
+}
+
+// Up to four independent dense p = 1 half-steps in ONE launch: the four updates of a Sinkhorn iteration (glhip_sinkhorn_iter4 with
+// p = 1, round 5; any D <= 16).  grid = (max row blocks, B, n_splits * count); problem k = blockIdx.z / n_splits.
+template <typename T>
+struct DistMulti {
+    DistParams<T> p[4];
+    int N[4], M[4];
+    long ws_stride;     // floats of split workspace per problem
+    int count;
+};
+
+template <int D, typename T, int NW>
+__global__ void __launch_bounds__(NW * 64, 4)
+dist_xd_multi_kernel(DistMulti<T> m, SplitInfo sp) {
+    using S = DistXdShape<D>;
+    __shared__ uint4 tile[S::kTile * S::NBP];
+    __shared__ __attribute__((aligned(16))) float tileS[S::kTile];
+    const int k = blockIdx.z / sp.n_splits;
+    const int split = blockIdx.z - k * sp.n_splits;
+    const int N = m.N[k], M = m.M[k];
+    if ((int)blockIdx.x * (NW * 32) >= N) return;
+    SplitInfo spk = sp;
+    spk.workspace += k * m.ws_stride;
+    spk.split_stride = (long)gridDim.y * N * 2;   // this problem's own row count
+    dist_xd_body<DM_SOFTMIN_P1, D, T, NW>(m.p[k], N, M, spk, (int)blockIdx.x, (int)blockIdx.y, split, tile, tileS);
 }
 
 

@@ -758,14 +758,49 @@ void launch_iter4_xd(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t s
         hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
 }
 
+// p = 1 (round 5): the multi launch of the dense distance kernel (glhip_dist_xd.h), any D <= 16
+template <int D, typename T>
+void launch_iter4_dist(SoftminMulti<T>& m, int B, float eps, const Scratch& sc, hipStream_t st) {
+    using MergeOp = SoftminFwdOp<D, 1, true, 1, T>;
+    constexpr int NW = 8, kRows = NW * 32;
+    const float s2 = kLog2e / eps;
+    DistMulti<T> dm;
+    dm.count = m.count;
+    int maxN = 0, minM = m.M[0];
+    long row_blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        const SoftminParams<T>& q = m.p[k];
+        dm.p[k] = DistParams<T>{q.x, q.y, q.h, q.pot, q.prev, q.out, s2, 1e-8f * s2 * s2, q.out_scale, q.pot_scale, q.alpha, q.beta, dist_guard()};
+        dm.N[k] = m.N[k];
+        dm.M[k] = m.M[k];
+        if (k >= m.count) continue;
+        maxN = m.N[k] > maxN ? m.N[k] : maxN;
+        minM = m.M[k] < minM ? m.M[k] : minM;
+        row_blocks += (long)B * ((m.N[k] + kRows - 1) / kRows);
+    }
+    const long per_split = (long)m.count * B * maxN * 2 * sizeof(float);
+    const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
+    SplitInfo sp;
+    sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    sp.workspace = static_cast<float*>(sc.ws);
+    sp.split_stride = 0;
+    sp.xcd_grid_x = 0;
+    sp.xcd_blocks = 0;
+    m.ws_stride = dm.ws_stride = (long)sp.n_splits * B * maxN * 2;
+    const int gx = (maxN + kRows - 1) / kRows;
+    hipLaunchKernelGGL((dist_xd_multi_kernel<D, T, NW>), dim3(gx, B, sp.n_splits * m.count), dim3(NW * 64), 0, st, dm, sp);
+    if (sp.n_splits > 1)
+        hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
+}
+
 template <typename T>
 int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
                 const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
-                int B, int N, int M, int D, float eps, float damping, int first, const Scratch& sc, hipStream_t st) {
+                int B, int N, int M, int D, float eps, float damping, int p, int first, const Scratch& sc, hipStream_t st) {
     // first = 0: averaged update;  1: initial potentials (no pot, no prev);  2: plain extrapolation (pot, no prev)
     const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
     auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
-        return make_softmin_params<T>(rows, cols, logw, out, eps, 2, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
+        return make_softmin_params<T>(rows, cols, logw, out, eps, p, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
     };
     SoftminMulti<T> m;
     m.count = f_aa_out ? 4 : 2;
@@ -776,6 +811,17 @@ int iter4_typed(const void* x, const void* y, const float* a_log, const float* b
         m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
     } else {
         m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+    }
+    if (p == 1) {      // distances: one kernel for every D <= 16
+        if (D == 1) launch_iter4_dist<1, T>(m, B, eps, sc, st);
+        else if (D == 2) launch_iter4_dist<2, T>(m, B, eps, sc, st);
+        else if (D == 3) launch_iter4_dist<3, T>(m, B, eps, sc, st);
+        else {
+#define GL_XD(DD) launch_iter4_dist<DD, T>(m, B, eps, sc, st)
+            GLHIP_XD_DISPATCH(D, GL_XD)
+#undef GL_XD
+        }
+        return GLHIP_OK;
     }
     if (D > 3) {      // 4 <= D <= 16 (round 5)
 #define GL_XD(DD) \

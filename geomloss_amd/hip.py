@@ -256,7 +256,7 @@ def sinkhorn_step_raw(x, y, logw, pot, prev, eps, damping, p=2, ranges=None, fla
     return out
 
 
-def sinkhorn_iter4_raw(x, y, a_log, b_log, pots, eps, damping, debias=True, flags=0):
+def sinkhorn_iter4_raw(x, y, a_log, b_log, pots, eps, damping, debias=True, flags=0, p=2):
     """The 4 (or 2) simultaneous updates of one Sinkhorn iteration in one launch.
 
     x (B,N,D), y (B,M,D); a_log (B,N), b_log (B,M); ``pots`` = None (initialisation) or the old potentials
@@ -275,7 +275,7 @@ def sinkhorn_iter4_raw(x, y, a_log, b_log, pots, eps, damping, debias=True, flag
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         rc = lib.glhip_sinkhorn_iter4(x.data_ptr(), y.data_ptr(), a_log.data_ptr(), b_log.data_ptr(),
                                       *[ptr(t) for t in old], *[ptr(t) for t in new], B, N, M, D, float(eps), float(damping),
-                                      2, _dtype_code(x), int(first), ptr(ws), nbytes, int(flags), _stream(x))
+                                      int(p), _dtype_code(x), int(first), ptr(ws), nbytes, int(flags), _stream(x))
     _check(rc, lib)
     return tuple(outs)
 
@@ -712,8 +712,8 @@ def softmin_value_and_grad(eps, x, y, h, guess, margin, ranges=None, flags=0):
     return _SoftminValueGrad.apply(x, y.detach(), h.detach(), float(eps), guess, m * 1.0001 + 1e-12, ranges, int(flags) | ENV_FLAGS)
 
 
-def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0):
-    """One whole iteration of the symmetric Sinkhorn loop on the GPU, non-differentiable (dense, p = 2, D <= 16).
+def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0, p=2):
+    """One whole iteration of the symmetric Sinkhorn loop on the GPU, non-differentiable (dense, p = 1 or 2, D <= 16).
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); a_log: (N,)|(1,N)|(B,N), b_log likewise; ``pots`` None (initial potentials)
     or the old ``(f_ba, g_ab, f_aa, g_bb)`` / ``(f_ba, g_ab)``.  Returns the new potentials, shaped like a_log / b_log."""
@@ -723,7 +723,7 @@ def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0)
     B = xb.shape[0]
     al = _f32(a_log).reshape(B, -1)
     old = None if pots is None else tuple(_f32(t).reshape(B, -1) for t in pots)
-    new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2)))
+    new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2)), p)
     shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)
     return tuple(t.view(sh) for t, sh in zip(new, shapes))
 
@@ -734,8 +734,9 @@ class Iter4Plan:
     previous one wrote, and outputs may not alias inputs).  At N ~ 1e3 the per-call Python work (checks, allocations,
     device guard) costs more than the kernels; the plan leaves one ctypes call per iteration."""
 
-    def __init__(self, x, y, a_log, b_log, debias=True, flags=0):
+    def __init__(self, x, y, a_log, b_log, debias=True, flags=0, p=2):
         self.lib = load_library()
+        self.p = int(p)
         xb, yb, bl, _ = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(b_log))
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
@@ -786,7 +787,7 @@ class Iter4Plan:
             old = old + (None,) * (4 - len(old))
         new = tuple(t.data_ptr() for t in outs) + (None,) * (4 - len(outs))
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.glhip_sinkhorn_iter4(*self.fixed, *old, *new, B, N, M, D, float(eps), float(damping), 2, self.dtype,
+        rc = self.lib.glhip_sinkhorn_iter4(*self.fixed, *old, *new, B, N, M, D, float(eps), float(damping), self.p, self.dtype,
                                            1 if pots is None else (2 if last else 0), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
                                            self.flags | self.extra_flags, stream)
         _check(rc, self.lib)
@@ -825,7 +826,7 @@ class _Last4(torch.autograd.Function):
                 continue
             h = logw + pot.reshape(B, -1) * (1.0 / eps)
             out = outs[i].reshape(B, -1) * (1.0 / damping)            # the soft-min value itself
-            gr = softmin_bwd_x_raw(rows, cols, h, out.contiguous(), (g.reshape(B, -1).float() * damping).contiguous(), eps, 2, None,
+            gr = softmin_bwd_x_raw(rows, cols, h, out.contiguous(), (g.reshape(B, -1).float() * damping).contiguous(), eps, plan.p, None,
                                    plan.flags | ctx.extra_flags)
             if i % 2 == 0:
                 gx = gr if gx is None else gx + gr

@@ -180,12 +180,14 @@ class _HipSoftmin:
 
     def _iter4_plan(self, C_xy, a_log, b_log, debias, create):
         """The hip.Iter4Plan of the loop being run, (re)built when the inputs change; None when the one-launch-per-iteration
-        path does not apply: block-sparse levels, p = 1, D > 16, and problems big enough for every soft-min to fill the GPU
+        path does not apply: block-sparse levels, D > 16, and problems big enough for every soft-min to fill the GPU
         on its own (those run faster as separate launches with pre-packed columns).  The coarse level of the multiscale
         backend (dense, ~2e3 clusters with their own weights) qualifies: its 7 x 4 soft-mins become 7 launches."""
         x, y = C_xy[0], C_xy[1]
-        if self.p != 2 or x.shape[-1] > hip.XD_MAX_DIM or not _fuse_iterations or x.dtype == torch.float64:
+        if self.p not in (1, 2) or x.shape[-1] > hip.XD_MAX_DIM or not _fuse_iterations or x.dtype == torch.float64:
             return None
+        if self.p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x)):
+            return None     # big p = 1 clouds: one voxel-sorted launch per soft-min (glhip_dist_x32.h) beats the fused iteration
         if hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16):
             return None     # the one-launch iteration exists on the default kernel only: a kernel-selection flag means "not that one"
         if self.multiscale and C_xy[4] is not None:     # truncated fine level: block-sparse launches
@@ -197,7 +199,7 @@ class _HipSoftmin:
         if plan is None or plan[0] is not x or plan[1] is not a_log or plan[2] is not b_log or plan[3] != debias:
             if not create:
                 return None
-            plan = self._plan = (x, a_log, b_log, debias, hip.Iter4Plan(x, y, a_log, b_log, debias))
+            plan = self._plan = (x, a_log, b_log, debias, hip.Iter4Plan(x, y, a_log, b_log, debias, p=self.p))
         return plan[4]
 
     def iter4(self, eps, C_xy, a_log, b_log, pots, damping, debias):

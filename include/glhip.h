@@ -167,7 +167,8 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
  * damping * softmin(eps, C, logw)  (`first` = 1: initial potentials, :461-465), or
  * damping * softmin(eps, C, logw + pot/eps)  (`first` = 2: the non-averaged last update, :612-623).  C_xy = C(x_i, y_j) etc. on the clouds x (B,N,D), y (B,M,D).
  *   f_aa / g_bb and their outputs may be NULL together (debias = False: two reductions).
- * Outputs must not alias inputs.  Dense, p = 2, D <= 16 (4 <= D <= 16 since round 5) (GLHIP_EUNSUPPORTED otherwise: issue four
+ * Outputs must not alias inputs.  Dense, D <= 16; p = 2 (4 <= D <= 16 since round 5) or p = 1 (round 5: the dense distance kernel
+ * of glhip_dist_xd.h) (GLHIP_EUNSUPPORTED otherwise: issue four
  * glhip_sinkhorn_step calls instead); meant for small and mid-size problems, where four separate launches
  * leave the chip under-filled.  Workspace: 4 * glhip_workspace_bytes(B, max(N,M), max(N,M), D, 0).
  */

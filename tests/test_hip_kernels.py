@@ -498,7 +498,8 @@ def test_fused_sinkhorn_step_equals_unfused_composition(cuda, N, M, D, B, p):
 @pytest.mark.parametrize("N,M,D,B", [(700, 900, 3, None), (130, 2100, 2, None), (257, 255, 1, 3), (3000, 40, 3, None),
                                      (600, 700, 5, None), (257, 255, 9, 3), (300, 1100, 16, None)])      # D > 3: the xd kernel's multi launch (round 5)
 @pytest.mark.parametrize("debias", [True, False])
-def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl):
+@pytest.mark.parametrize("p", [2, 1])
+def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl, p):
     """glhip_sinkhorn_iter4 (one launch per Sinkhorn iteration) == the simultaneous glhip_sinkhorn_step calls it replaces,
     for the initialisation and for an averaged update, with and without the two debiasing reductions."""
     x, y, _ = _clouds(90 + N, N, M, D, B=B)
@@ -506,29 +507,32 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl):
     sh = (lambda n: (n,)) if B is None else (lambda n: (B, n))
     a_log = np.log(rng.random(sh(N)) + 0.1).astype(np.float32)
     b_log = np.log(rng.random(sh(M)) + 0.1).astype(np.float32)
-    eps, damping = 0.02, 0.9
+    if p == 1 and fl:
+        pytest.skip("the f16 x 2 layout is a p = 2 layout")
+    eps, damping = (0.02 if p == 2 else 0.1), 0.9
+    tol = 2e-6 if p == 2 else 4e-6      # p = 1: the iteration runs the MFMA distance kernel, the half-steps of D <= 3 explicit differences
     xt, yt, al, bl = _t(x, cuda), _t(y, cuda), _t(a_log, cuda), _t(b_log, cuda)
-    step = lambda rows, cols, lw, pot, prev: hip.sinkhorn_step(eps, rows, cols, lw, pot, prev, damping, flags=fl)  # noqa: E731
+    step = lambda rows, cols, lw, pot, prev: hip.sinkhorn_step(eps, rows, cols, lw, pot, prev, damping, p=p, flags=fl)  # noqa: E731
 
-    init = hip.sinkhorn_iter4(eps, xt, yt, al, bl, None, damping, debias, flags=fl)
+    init = hip.sinkhorn_iter4(eps, xt, yt, al, bl, None, damping, debias, flags=fl, p=p)
     want = [step(xt, yt, bl, None, None), step(yt, xt, al, None, None)]
     if debias:
         want += [step(xt, xt, al, None, None), step(yt, yt, bl, None, None)]
     assert len(init) == len(want)
     for got, ref in zip(init, want):
-        assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-6
-    ref_np = oracle_c.softmin(eps, *(a if B is None else a[0] for a in (x, y, b_log)), 2) * damping
+        assert got.shape == ref.shape and (got - ref).abs().max().item() < tol
+    ref_np = oracle_c.softmin(eps, *(a if B is None else a[0] for a in (x, y, b_log)), p) * damping
     assert np.abs((init[0] if B is None else init[0][0]).cpu().numpy() - ref_np).max() < 4e-7 * D + 2e-6 * np.abs(ref_np).max()
 
     f_ba, g_ab = want[0] + 0.01, want[1] - 0.02          # any old potentials
     f_aa, g_bb = (want[2] * 0.5, want[3] * 0.7) if debias else (None, None)
     old = (f_ba, g_ab, f_aa, g_bb) if debias else (f_ba, g_ab)
-    new = hip.sinkhorn_iter4(eps, xt, yt, al, bl, old, damping, debias, flags=fl)
+    new = hip.sinkhorn_iter4(eps, xt, yt, al, bl, old, damping, debias, flags=fl, p=p)
     want2 = [step(xt, yt, bl, g_ab, f_ba), step(yt, xt, al, f_ba, g_ab)]
     if debias:
         want2 += [step(xt, xt, al, f_aa, f_aa), step(yt, yt, bl, g_bb, g_bb)]
     for got, ref in zip(new, want2):
-        assert (got - ref).abs().max().item() < 2e-6
+        assert (got - ref).abs().max().item() < tol
     # simultaneous updates: outputs may not alias inputs (raw entry point)
     lib = hip.load_library()
     xb, yb = (xt, yt) if B is not None else (xt[None], yt[None])
