@@ -121,9 +121,10 @@ def native_clustering_applies(x, labels=None):
             and x.dtype in (torch.float32, torch.bfloat16) and hip.library_available())
 
 
-def clusterize_device_many(clouds, scale, pre_div=1.0):
+def clusterize_device_many(clouds, scale, pre_div=1.0, long_perm=True):
     """:func:`clusterize_device` for several weighted clouds ``[(a, x), ...]`` with ONE host round trip for all their cluster counts
-    (the two measures of a two-scale loss: one synchronisation instead of two)."""
+    (the two measures of a two-scale loss: one synchronisation instead of two).  ``long_perm=False``: the permutations stay int32,
+    as the kernel wrote them, for callers that only index with them now and then (one launch less per cloud)."""
     from . import hip
     pending = []
     for a, x in clouds:
@@ -135,7 +136,7 @@ def clusterize_device_many(clouds, scale, pre_div=1.0):
     out = []
     for (a, x, need_graph, (_, finish)), values in zip(pending, counts):
         perm32, xs, ws, ranges, cents, w_c = finish(values)
-        perm = perm32.long()
+        perm = perm32.long() if (long_perm or need_graph) else perm32
         if need_graph:
             xs, ws = x[perm], (None if a is None else a[perm])
         elif a is not None and a.dtype != torch.float32:

@@ -1,5 +1,5 @@
 // glhip_api.hip — C-ABI of libgeomloss_hip.so (include/glhip.h), part 1: version / errors / scratch size and the soft-min FORWARD family
-// (glhip_softmin_fwd, glhip_sinkhorn_step, glhip_sinkhorn_iter4).  gfx950 only.
+// (glhip_softmin_fwd, glhip_sinkhorn_step, glhip_sinkhorn_iter4, glhip_sinkhorn_extrapolate4).  gfx950 only.
 #include "glhip_launch.h"
 
 namespace glhip {
@@ -145,6 +145,31 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
              ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st)
              : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st);
     return rc ? rc : check_launch("glhip_sinkhorn_iter4");
+}
+
+int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, const void* yc, const float* a_log_c, const float* b_log_c,
+                                const float* f_ba, const float* g_ab, const float* f_aa, const float* g_bb, float* f_ba_out,
+                                float* g_ab_out, float* f_aa_out, float* g_bb_out, int B, int N, int M, int Nc, int Mc, int D, float eps,
+                                float damping, int p, int in_dtype, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    const char* fn = "glhip_sinkhorn_extrapolate4";
+    int rc = check_common(fn, x, yc, b_log_c, B, N, Mc, D, in_dtype, nullptr, nullptr, nullptr, 0);
+    if (!rc) rc = check_common(fn, y, xc, a_log_c, B, M, Nc, D, in_dtype, nullptr, nullptr, nullptr, 0);
+    if (rc) return rc;
+    if ((p != 1 && p != 2) || D > kXdMaxD) return fail(GLHIP_EUNSUPPORTED, "%s: only p = 1, 2 and D <= 16 (got p = %d, D = %d)", fn, p, D);
+    if (flags & (GLHIP_FLAG_DIRECT | GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_F32_MFMA | GLHIP_FLAG_XDL16))
+        return fail(GLHIP_EUNSUPPORTED, "%s: runs on the default 32x32x16 kernel only (flags = %d)", fn, flags);
+    if (B == 0 || (N == 0 && M == 0)) return GLHIP_OK;
+    if (Nc == 0 || Mc == 0) return fail(GLHIP_EINVAL, "%s: empty coarse measure (Nc = %d, Mc = %d)", fn, Nc, Mc);
+    if (!f_ba_out || !g_ab_out || !f_ba || !g_ab) return fail(GLHIP_EINVAL, "%s: NULL f_ba / g_ab / f_ba_out / g_ab_out", fn);
+    if ((f_aa_out == nullptr) != (g_bb_out == nullptr)) return fail(GLHIP_EINVAL, "%s: f_aa_out and g_bb_out go together", fn);
+    if (f_aa_out && (!f_aa || !g_bb)) return fail(GLHIP_EINVAL, "%s: NULL f_aa / g_bb", fn);
+    if (!(eps > 0.f)) return fail(GLHIP_EINVAL, "%s: eps must be > 0", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Scratch sc = make_scratch(workspace, workspace_bytes, flags & ~GLHIP_FLAG_PREPACK, 0, N > M ? N : M);
+    rc = (in_dtype == GLHIP_F32)
+             ? extrapolate4_typed<float>(x, y, xc, yc, a_log_c, b_log_c, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, Nc, Mc, D, eps, damping, p, sc, st)
+             : extrapolate4_typed<bf16_t>(x, y, xc, yc, a_log_c, b_log_c, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, Nc, Mc, D, eps, damping, p, sc, st);
+    return rc ? rc : check_launch(fn);
 }
 
 }  // extern "C"

@@ -39,6 +39,15 @@ __device__ __forceinline__ int voxel_of(const T* __restrict__ x, long idx, float
     return (int)floorf((to_f32<T>(x[idx]) / pre_div) / voxel);
 }
 
+// the workspace head in its start state (one launch; three hipMemsetAsync calls were four fill kernels)
+__global__ void head_init_kernel(ClusterHead* head) {
+    const int t = threadIdx.x;
+    if (t < 3) head->qmin[t] = INT_MAX;
+    else if (t < 6) head->qmax[t - 3] = INT_MIN;
+    else if (t == 6) head->overflow = 0;
+    else if (t == 7) head->pad = 0;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) bounds_kernel(const T* __restrict__ x, int N, int D, float pre_div, float voxel, ClusterHead* head) {
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
@@ -96,7 +105,8 @@ __global__ void __launch_bounds__(256) flags_kernel(const uint64_t* __restrict__
 }
 
 // labels (inclusive scan of the flags) -> [start, end) of every cluster, and the cluster count
-__global__ void __launch_bounds__(256) ranges_kernel(const int32_t* __restrict__ incl, int N, int32_t* __restrict__ ranges, int32_t* n_clusters) {
+__global__ void __launch_bounds__(256) ranges_kernel(const int32_t* __restrict__ incl, int N, int32_t* __restrict__ ranges, int32_t* n_clusters,
+                                                     const ClusterHead* __restrict__ head) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const int c = incl[i] - 1;
@@ -107,6 +117,7 @@ __global__ void __launch_bounds__(256) ranges_kernel(const int32_t* __restrict__
     if (i == N - 1) {
         ranges[2 * c + 1] = N;
         n_clusters[0] = c + 1;
+        n_clusters[1] = head->overflow;     // the overflow flag of keys_kernel travels with the cluster count
     }
 }
 
@@ -194,9 +205,7 @@ int grid_cluster_typed(const void* x_, const float* w, int N, int D, float pre_d
     void* tmp = ws + off;
 
     const int blocks = (N + 255) / 256;
-    (void)hipMemsetAsync(head->qmin, 0x7f, sizeof(head->qmin), st);     // INT-large
-    (void)hipMemsetAsync(head->qmax, 0x80, sizeof(head->qmax), st);     // INT-small
-    (void)hipMemsetAsync(&head->overflow, 0, 2 * sizeof(int), st);
+    hipLaunchKernelGGL(head_init_kernel, dim3(1), dim3(64), 0, st, head);
     hipLaunchKernelGGL((bounds_kernel<T>), dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, x, N, D, pre_div, voxel, head);
     hipLaunchKernelGGL((keys_kernel<T>), dim3(blocks), dim3(256), 0, st, x, N, D, pre_div, voxel, head, keys_in, idx_in);
     // rocPRIM's radix sort is stable: equal keys (one voxel) keep the order of their indices, as torch.sort(stable=True) does
@@ -206,13 +215,14 @@ int grid_cluster_typed(const void* x_, const float* w, int N, int D, float pre_d
     int32_t* incl = idx_in;   // the unsorted indices are no longer needed
     if (rocprim::inclusive_scan(tmp, temp_scan, flags, incl, (size_t)N, rocprim::plus<int32_t>(), st) != hipSuccess)
         return fail(GLHIP_ELAUNCH, "glhip_grid_cluster: scan failed: %s", hipGetErrorString(hipGetLastError()));
-    hipLaunchKernelGGL(ranges_kernel, dim3(blocks), dim3(256), 0, st, incl, N, ranges, n_clusters);
-    hipLaunchKernelGGL((centroids_kernel<T>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, x, w, perm, ranges, n_clusters, D, pre_div,
+    hipLaunchKernelGGL(ranges_kernel, dim3(blocks), dim3(256), 0, st, incl, N, ranges, n_clusters, head);
+    // one wavefront per cluster, the count known on the device only: a wavefront per 4 points covers the fine grids of small clouds
+    // in one round (a cluster loop of 7 rounds cost 50 us at N = 1e4), surplus wavefronts leave at once
+    const int blocks_c = (N + 15) / 16;
+    hipLaunchKernelGGL((centroids_kernel<T>), dim3(blocks_c < 2048 ? blocks_c : 2048), dim3(256), 0, st, x, w, perm, ranges, n_clusters, D, pre_div,
                        centroids, weights_c);
     if (x_sorted)
         hipLaunchKernelGGL((gather_kernel<T>), dim3(blocks), dim3(256), 0, st, x, w, perm, N, D, static_cast<T*>(x_sorted), w_sorted);
-    // the overflow flag travels with the cluster count: n_clusters[1]
-    (void)hipMemcpyAsync(n_clusters + 1, &head->overflow, sizeof(int), hipMemcpyDeviceToDevice, st);
     return check_launch("glhip_grid_cluster");
 }
 
@@ -313,44 +323,52 @@ __global__ void __launch_bounds__(256) runs_kernel(KeepRule rule, int Cr, int Cc
     if (!FILL && lane == 0) counts[i] = n_starts;
 }
 
-// Pairs of POINTS a keep rule retains, without building its intervals: one wavefront per row cluster adds
-// (rows of the cluster) x (columns of the kept column clusters).
-__global__ void __launch_bounds__(256) kept_pairs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_rows,
-                                                         const int32_t* __restrict__ ranges_cols, unsigned long long* __restrict__ kept) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int ii = i < Cr ? i : Cr - 1;
-    long long cols = 0;
-    for (int c0 = 0; c0 < Cc; c0 += 256) {
+// Pairs of POINTS a keep rule retains, without building its intervals: a wavefront per (row cluster, slab of 256 column clusters)
+// adds (rows of the cluster) x (columns of the kept column clusters).  Round 5: a fixed number of workgroups walks the items and
+// adds its total with ONE atomic — with one workgroup per 4 row clusters the ~500 same-address atomics of a launch (each a trip to
+// memory: the 8 L2s do not share lines) cost 40 us of a 45 us launch, a 2-D grid with 3000 of them 57 us.
+constexpr int kKeptBlocks = 512, kKeptWaves = 16;      // ~15 ns per atomic against ~1 us per item of a wavefront's walk: 2000 x 2000 clusters -> 2 items each
+
+__global__ void kept_zero_kernel(unsigned long long* kept) {
+    if (threadIdx.x < 3) kept[threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(64 * kKeptWaves) kept_pairs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_rows,
+                                                                    const int32_t* __restrict__ ranges_cols, unsigned long long* __restrict__ kept) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_slabs = (Cc + 255) / 256;
+    const long n_items = (long)Cr * n_slabs;
+    unsigned long long acc = 0;
+    for (long item = (long)blockIdx.x * kKeptWaves + wave; item < n_items; item += (long)gridDim.x * kKeptWaves) {
+        const int i = (int)(item / n_slabs), c0 = (int)(item - (long)i * n_slabs) * 256;
+        long long cols = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + 64 * u + lane, cc = min(c, Cc - 1);      // unconditional loads, masked afterwards
             const int len = ranges_cols[2 * cc + 1] - ranges_cols[2 * cc];
-            cols += (keep_pair(rule, ii, cc) && c < Cc) ? len : 0;
+            cols += (keep_pair(rule, i, cc) && c < Cc) ? len : 0;
         }
+        acc += (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * i + 1] - ranges_rows[2 * i]);
     }
-    for (int off = 32; off > 0; off >>= 1) cols += __shfl_xor(cols, off, 64);
-    __shared__ unsigned long long part[4];
-    part[threadIdx.x >> 6] = (unsigned long long)cols * (unsigned long long)(ranges_rows[2 * ii + 1] - ranges_rows[2 * ii]);   // rows beyond Cr: not summed below
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ unsigned long long part[kKeptWaves];
+    if (lane == 0) part[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = 0, sq = 0;
-        for (int w = 0; w < 4 && blockIdx.x * 4 + w < Cr; ++w) {
-            t += part[w];
-            const unsigned long long n = (unsigned long long)(ranges_rows[2 * (blockIdx.x * 4 + w) + 1] - ranges_rows[2 * (blockIdx.x * 4 + w)]);
-            sq += n * n;
-        }
+        unsigned long long t = 0;
+        for (int w = 0; w < kKeptWaves; ++w) t += part[w];
         if (t) atomicAdd(kept, t);
-        atomicAdd(kept + 1, sq);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {      // the same statistic of the column clusters, once
+    if (blockIdx.x == 0 && wave < 2) {      // the sums of squared cluster sizes, rows (wavefront 0) and columns (wavefront 1), once
+        const int32_t* rg = wave == 0 ? ranges_rows : ranges_cols;
+        const int C = wave == 0 ? Cr : Cc;
         unsigned long long sq = 0;
-        for (int c = lane; c < Cc; c += 64) {
-            const unsigned long long m = (unsigned long long)(ranges_cols[2 * c + 1] - ranges_cols[2 * c]);
+        for (int c = lane; c < C; c += 64) {
+            const unsigned long long m = (unsigned long long)(rg[2 * c + 1] - rg[2 * c]);
             sq += m * m;
         }
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        if (lane == 0) kept[2] = sq;
+        if (lane == 0) kept[1 + wave] = sq;
     }
 }
 
@@ -469,12 +487,14 @@ int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols
     if (kind == GLHIP_KEEP_DUAL_SLACK && p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_block_ranges_kept_pairs: p must be 1 or 2");
     if (!kept) return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL kept");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    (void)hipMemsetAsync(kept, 0, 3 * sizeof(long long), st);
+    hipLaunchKernelGGL(kept_zero_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(kept));      // (a 24-byte hipMemsetAsync is two fill kernels)
     if (Cr == 0 || Cc == 0) return GLHIP_OK;
     if (!rows || !cols || !ranges_rows || !ranges_cols || (kind == GLHIP_KEEP_DUAL_SLACK && (!f || !g)))
         return fail(GLHIP_EINVAL, "glhip_block_ranges_kept_pairs: NULL pointer");
     const KeepRule rule{kind, rows, cols, f, g, D, p, thr};
-    hipLaunchKernelGGL(kept_pairs_kernel, dim3((Cr + 3) / 4), dim3(256), 0, st, rule, Cr, Cc, ranges_rows, ranges_cols,
+    const long items = (long)Cr * ((Cc + 255) / 256);
+    const long want = (items + kKeptWaves - 1) / kKeptWaves;
+    hipLaunchKernelGGL(kept_pairs_kernel, dim3(want < kKeptBlocks ? (unsigned)want : kKeptBlocks), dim3(64 * kKeptWaves), 0, st, rule, Cr, Cc, ranges_rows, ranges_cols,
                        reinterpret_cast<unsigned long long*>(kept));
     return check_launch("glhip_block_ranges_kept_pairs");
 }

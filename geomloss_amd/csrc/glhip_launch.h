@@ -692,6 +692,11 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    // ... with at least 3 column tiles per split: a 128-row workgroup that runs one tile of 512 columns is mostly prologue and
+    // epilogue (N = M = 1e4, 19 splits by the rule: 64 us per iteration; 6: 57 us; 2e4: 173 -> 166 us; 5e3 and 3e4: unchanged)
+    if (minM >= 3072 && minM / sp.n_splits < 1536) sp.n_splits = minM / 1536;
+    static const int force_splits = getenv("GLHIP_ITER4_SPLITS") ? atoi(getenv("GLHIP_ITER4_SPLITS")) : 0;   // tuning knob
+    if (force_splits > 0 && sc.allow_split && fit >= force_splits && minM / force_splits >= 64) sp.n_splits = force_splits;
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;   // per problem, set in the kernels
     sp.xcd_grid_x = 0;
@@ -793,24 +798,11 @@ void launch_iter4_dist(SoftminMulti<T>& m, int B, float eps, const Scratch& sc, 
         hipLaunchKernelGGL((merge_multi_kernel<MergeOp, T>), dim3((maxN + kBlock - 1) / kBlock, B, m.count), dim3(kBlock), 0, st, m, sp);
 }
 
+// every problem of a SoftminMulti in one launch, on the kernel family of (p, D, layout)
 template <typename T>
-int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
-                const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
-                int B, int N, int M, int D, float eps, float damping, int p, int first, const Scratch& sc, hipStream_t st) {
-    // first = 0: averaged update;  1: initial potentials (no pot, no prev);  2: plain extrapolation (pot, no prev)
-    const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
-    auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
-        return make_softmin_params<T>(rows, cols, logw, out, eps, p, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
-    };
-    SoftminMulti<T> m;
-    m.count = f_aa_out ? 4 : 2;
-    m.p[0] = one(x, y, b_log, g_ab, f_ba, f_ba_out); m.N[0] = N; m.M[0] = M;
-    m.p[1] = one(y, x, a_log, f_ba, g_ab, g_ab_out); m.N[1] = M; m.M[1] = N;
-    if (m.count == 4) {
-        m.p[2] = one(x, x, a_log, f_aa, f_aa, f_aa_out); m.N[2] = N; m.M[2] = N;
-        m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
-    } else {
-        m.p[2] = m.p[3] = m.p[0]; m.N[2] = m.N[3] = 0; m.M[2] = m.M[3] = M;
+int multi_dispatch(SoftminMulti<T>& m, int B, int D, float eps, int p, const Scratch& sc, hipStream_t st) {
+    if (m.count < 4) {      // unused slots: no rows
+        for (int k = m.count; k < 4; ++k) { m.p[k] = m.p[0]; m.N[k] = 0; m.M[k] = m.M[0]; }
     }
     if (p == 1) {      // distances: one kernel for every D <= 16
         if (D == 1) launch_iter4_dist<1, T>(m, B, eps, sc, st);
@@ -841,6 +833,48 @@ int iter4_typed(const void* x, const void* y, const float* a_log, const float* b
     else if (D == 2) launch_iter4<2, T>(m, B, sc, st);
     else launch_iter4<3, T>(m, B, sc, st);
     return GLHIP_OK;
+}
+
+template <typename T>
+int iter4_typed(const void* x, const void* y, const float* a_log, const float* b_log, const float* f_ba, const float* g_ab,
+                const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
+                int B, int N, int M, int D, float eps, float damping, int p, int first, const Scratch& sc, hipStream_t st) {
+    // first = 0: averaged update;  1: initial potentials (no pot, no prev);  2: plain extrapolation (pot, no prev)
+    const float alpha = first ? damping : 0.5f * damping, beta = 0.5f;
+    auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, const float* prev, float* out) {
+        return make_softmin_params<T>(rows, cols, logw, out, eps, p, first == 1 ? nullptr : pot, first ? nullptr : prev, alpha, beta);
+    };
+    SoftminMulti<T> m;
+    m.count = f_aa_out ? 4 : 2;
+    m.p[0] = one(x, y, b_log, g_ab, f_ba, f_ba_out); m.N[0] = N; m.M[0] = M;
+    m.p[1] = one(y, x, a_log, f_ba, g_ab, g_ab_out); m.N[1] = M; m.M[1] = N;
+    if (m.count == 4) {
+        m.p[2] = one(x, x, a_log, f_aa, f_aa, f_aa_out); m.N[2] = N; m.M[2] = N;
+        m.p[3] = one(y, y, b_log, g_bb, g_bb, g_bb_out); m.N[3] = M; m.M[3] = M;
+    }
+    return multi_dispatch<T>(m, B, D, eps, p, sc, st);
+}
+
+// The coarse-to-fine jump of the two-scale loop: every potential carried from the coarse measures to the fine points,
+//     f_ba(x_i) = damping * softmin(eps, C(x_i, y_c), b_log_c + g_ab_c / eps)   and its three companions,
+// as ONE launch of the same multi kernels (rows: fine clouds, columns: coarse clouds).
+template <typename T>
+int extrapolate4_typed(const void* x, const void* y, const void* xc, const void* yc, const float* a_log_c, const float* b_log_c,
+                       const float* f_ba, const float* g_ab, const float* f_aa, const float* g_bb, float* f_ba_out, float* g_ab_out,
+                       float* f_aa_out, float* g_bb_out, int B, int N, int M, int Nc, int Mc, int D, float eps, float damping, int p,
+                       const Scratch& sc, hipStream_t st) {
+    auto one = [&](const void* rows, const void* cols, const float* logw, const float* pot, float* out) {
+        return make_softmin_params<T>(rows, cols, logw, out, eps, p, pot, nullptr, damping, 0.5f);
+    };
+    SoftminMulti<T> m;
+    m.count = f_aa_out ? 4 : 2;
+    m.p[0] = one(x, yc, b_log_c, g_ab, f_ba_out); m.N[0] = N; m.M[0] = Mc;
+    m.p[1] = one(y, xc, a_log_c, f_ba, g_ab_out); m.N[1] = M; m.M[1] = Nc;
+    if (m.count == 4) {
+        m.p[2] = one(x, xc, a_log_c, f_aa, f_aa_out); m.N[2] = N; m.M[2] = Nc;
+        m.p[3] = one(y, yc, b_log_c, g_bb, g_bb_out); m.N[3] = M; m.M[3] = Mc;
+    }
+    return multi_dispatch<T>(m, B, D, eps, p, sc, st);
 }
 
 struct StepArgs {   // fused Sinkhorn half-step; all-default = plain soft-min

@@ -40,6 +40,7 @@ SIGNATURES = {
                                      _c_int, _c_int] + _RANGES + _TAIL),
     "glhip_sinkhorn_iter4": (_c_int, [_vp] * 12 + [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int, _c_int]
                              + _TAIL),
+    "glhip_sinkhorn_extrapolate4": (_c_int, [_vp] * 14 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_int] + _TAIL),
     "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
                                      _c_int] + _RANGES + _TAIL),
     "glhip_kernel_conv_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int]
@@ -280,6 +281,28 @@ def sinkhorn_iter4_raw(x, y, a_log, b_log, pots, eps, damping, debias=True, flag
     return tuple(outs)
 
 
+def sinkhorn_extrapolate4_raw(x, y, xc, yc, a_log_c, b_log_c, pots, eps, damping, flags=0, p=2):
+    """The coarse-to-fine jump in one launch (``glhip_sinkhorn_extrapolate4``): fine clouds x (B,N,D), y (B,M,D), coarse clouds
+    xc (B,Nc,D), yc (B,Mc,D) with log-weights a_log_c (B,Nc), b_log_c (B,Mc) and potentials ``pots`` = (f_ba, g_ab, f_aa, g_bb) /
+    (f_ba, g_ab) on the coarse clouds.  Returns the potentials on the fine clouds, same arity."""
+    lib = load_library()
+    B, N, D = x.shape
+    M, Nc, Mc = y.shape[1], xc.shape[1], yc.shape[1]
+    debias = len(pots) == 4
+    outs = [torch.empty((B, n), dtype=torch.float32, device=x.device) for n in ((N, M, N, M) if debias else (N, M))]
+    old = [t.data_ptr() for t in pots] + [None] * (4 - len(pots))
+    new = [t.data_ptr() for t in outs] + [None] * (4 - len(outs))
+    with torch.cuda.device(x.device):
+        L = max(N, M, Nc, Mc)
+        nbytes = 4 * int(lib.glhip_workspace_bytes(B, L, L, D, 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        rc = lib.glhip_sinkhorn_extrapolate4(x.data_ptr(), y.data_ptr(), xc.data_ptr(), yc.data_ptr(), a_log_c.data_ptr(), b_log_c.data_ptr(),
+                                             *old, *new, B, N, M, Nc, Mc, D, float(eps), float(damping), int(p), _dtype_code(x),
+                                             None if ws is None else ws.data_ptr(), nbytes, int(flags), _stream(x))
+    _check(rc, lib)
+    return tuple(outs)
+
+
 def softmin_bwd_x_raw(x, y, h, out, grad_out, eps, p=2, ranges=None, flags=0):
     lib = load_library()
     B, N, D = x.shape
@@ -388,7 +411,8 @@ def softmin_dense_fwd_raw(C, h, eps):
 
 def read_back(*tensors):
     """ONE host round trip for several small device tensors (cluster counts, kept-pair counts): their values as lists of ints."""
-    flat = torch.cat([t.reshape(-1).to(torch.int64) for t in tensors]).tolist()
+    same = all(t.dtype == tensors[0].dtype for t in tensors)      # (int32 cluster counts, int64 pair counts: no conversion launches)
+    flat = torch.cat([t.reshape(-1) if same else t.reshape(-1).to(torch.int64) for t in tensors]).tolist()
     out, o = [], 0
     for t in tensors:
         out.append([int(v) for v in flat[o:o + t.numel()]])
@@ -726,6 +750,22 @@ def sinkhorn_iter4(eps, x, y, a_log, b_log, pots, damping, debias=True, flags=0,
     new = sinkhorn_iter4_raw(xb, yb, al, bl, old, eps, damping, debias, int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2)), p)
     shapes = (a_log.shape, b_log.shape, a_log.shape, b_log.shape)
     return tuple(t.view(sh) for t, sh in zip(new, shapes))
+
+
+def sinkhorn_extrapolate4(eps, x, y, xc, yc, a_log_c, b_log_c, pots, damping, flags=0, p=2):
+    """Coarse-to-fine jump of the two-scale loop on the GPU, non-differentiable: every potential of ``pots`` — (f_ba, g_ab, f_aa, g_bb)
+    or (f_ba, g_ab), living on the coarse clouds xc (Nc,D), yc (Mc,D) — carried to the fine clouds x (N,D), y (M,D) by one soft-min
+    against the coarse measure each, in ONE launch (dense, p = 1 or 2, D <= 16).  Batched (B,.,D) clouds alike."""
+    pts = [_points(t.detach(), n) for t, n in ((x, "x"), (y, "y"), (xc, "xc"), (yc, "yc"))]
+    if any(t.dtype != pts[0].dtype for t in pts):
+        pts = [t.to(pts[0].dtype) for t in pts]
+    batched = pts[0].dim() == 3
+    xb, yb, xcb, ycb = (t if batched else t[None] for t in pts)
+    B = xb.shape[0]
+    row = lambda t: _f32(t).reshape(B, -1)      # noqa: E731
+    outs = sinkhorn_extrapolate4_raw(xb, yb, xcb, ycb, row(a_log_c), row(b_log_c), tuple(row(t) for t in pots), eps, damping,
+                                     int(flags) | (ENV_FLAGS & (FLAG_NO_SPLIT | FLAG_F16X2)), p)
+    return outs if batched else tuple(t.view(-1) for t in outs)
 
 
 class Iter4Plan:

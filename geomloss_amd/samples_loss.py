@@ -7,7 +7,7 @@ backends run on the HIP kernels of this package (MI355X); ``tensorized`` is dens
 """
 
 import warnings
-from functools import partial
+from functools import lru_cache, partial
 
 import torch
 from torch.nn import Module
@@ -27,6 +27,13 @@ routines = {
 }
 for _name in ("energy", "gaussian", "laplacian"):
     routines[_name] = {bk: partial(fn, name=_name) for bk, fn in _KERNEL_DRIVERS.items()}
+
+
+@lru_cache(maxsize=256)
+def _uniform_weight(N, dtype):
+    """``(torch.ones(N, dtype=dtype) / N)[0]`` as a Python float: the quotient rounded once in ``dtype`` (IEEE division for float32 /
+    float64, computed in float32 and rounded for the half types — on the CPU as on the GPU), exactly representable in it."""
+    return (torch.ones((), dtype=dtype) / N).item()
 
 
 def _squeeze_trailing_unit(w, other, ndim_flat, msg_both, msg_w, msg_other):
@@ -181,12 +188,13 @@ class SamplesLoss(Module):
         # Uniform weights 1/N (``samples_loss.py:325-335``), created on the device of x: the reference builds them on the CPU
         # and copies (`torch.ones(N).type_as(x)`), a pageable host-to-device copy that stalls the HIP queue for ~90 ms every
         # few calls (measured: a 3.5-ms batched loss spiking to 90-190 ms, tools/probe_spikes2.py).
+        # One fill launch: the value is `1 / N` rounded as that division rounds it in the dtype of x (_uniform_weight).
         if x.dim() == 2:
             N = x.shape[0]
-            return torch.ones(N, dtype=x.dtype, device=x.device) / N
+            return torch.full((N,), _uniform_weight(N, x.dtype), dtype=x.dtype, device=x.device)
         if x.dim() == 3:
             B, N, _ = x.shape
-            return torch.ones((B, N), dtype=x.dtype, device=x.device) / N
+            return torch.full((B, N), _uniform_weight(N, x.dtype), dtype=x.dtype, device=x.device)
         raise ValueError("Input samples 'x' and 'y' should be encoded as (N,D) or (B,N,D) (batch) tensors.")
 
     def check_shapes(self, l_x, α, x, l_y, β, y):

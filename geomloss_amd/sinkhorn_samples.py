@@ -23,7 +23,7 @@ import torch
 from . import hip
 from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, clusterize_device_many, from_matrix,
                       grid_cluster, kept_pairs_device, native_clustering_applies, swap_axes)
-from .sinkhorn_divergence import log_weights, scaling_parameters, sinkhorn_cost, sinkhorn_loop
+from .sinkhorn_divergence import log_weights, log_weights_many, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
 # ==============================================================================
@@ -210,6 +210,17 @@ class _HipSoftmin:
         plan.extra_flags = self._flags(eps)
         return plan.run(eps, damping, pots)
 
+    def extrapolate4(self, pots, eps, damping, C_xy, C_yx, a_log, b_log, C_xy_fine, C_yx_fine, debias):
+        """The coarse-to-fine jump of every potential as one launch (``glhip_sinkhorn_extrapolate4``), or None where the fused
+        iterations do not apply either (D > 16, float64 clouds, a kernel-selection flag in the environment, fusion switched off).
+        ``a_log`` / ``b_log``: the log-weights of the COARSE measures, ``pots`` the potentials on them."""
+        x_, y_, xc, yc = C_xy_fine[0], C_yx_fine[0], C_xy[0], C_yx[0]
+        if (self.p not in (1, 2) or x_.shape[-1] > hip.XD_MAX_DIM or not _fuse_iterations
+                or any(t.dtype == torch.float64 for t in (x_, y_, xc, yc))
+                or hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16)):
+            return None
+        return hip.sinkhorn_extrapolate4(eps, x_, y_, xc, yc, a_log, b_log, pots, damping, flags=self._flags(eps), p=self.p)
+
     def last4(self, eps, C_xy, C_yx, a_log, b_log, pots, damping, debias, create=False):
         """The differentiable, non-averaged last update of every potential as one forward launch (and one autograd node);
         None when :meth:`iter4` did not run this loop (unless ``create``)."""
@@ -269,7 +280,7 @@ def sinkhorn_online(
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
     softmin.set_range(diameter, measured=not diameter_given)
 
-    a_log, b_log = log_weights(a), log_weights(b)
+    a_log, b_log = log_weights_many([a, b])
     # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
     # capture does not allow — and launches of that size gain nothing from a graph)
     sorts = p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x))
@@ -493,6 +504,7 @@ def sinkhorn_multiscale(
     p_kernel = _exponent_of(cost_formula)
     softmin = _HipSoftmin(p_kernel, multiscale=True)
     extrapolate = partial(extrapolate_samples, softmin=softmin)
+    extrapolate.all4 = softmin.extrapolate4     # the loop's one-launch hook (sinkhorn_divergence.sinkhorn_loop)
 
     diameter_given = diameter is not None
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
@@ -502,7 +514,7 @@ def sinkhorn_multiscale(
     if cluster_scale is None:
         cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
     if native_clustering_applies(x, labels_x) and native_clustering_applies(y, labels_y):      # both clusterings, one host round trip
-        (a_c, a, x_c, x, ranges_x, perm_x), (b_c, b, y_c, y, ranges_y, perm_y) = clusterize_device_many([(a, x), (b, y)], cluster_scale)
+        (a_c, a, x_c, x, ranges_x, perm_x), (b_c, b, y_c, y, ranges_y, perm_y) = clusterize_device_many([(a, x), (b, y)], cluster_scale, long_perm=False)
     else:
         [a_c, a], [x_c, x], [ranges_x], perm_x = clusterize(a, x, scale=cluster_scale, labels=labels_x)
         [b_c, b], [y_c, y], [ranges_y], perm_y = clusterize(b, y, scale=cluster_scale, labels=labels_y)
@@ -529,8 +541,8 @@ def sinkhorn_multiscale(
                 )
             )
 
-    a_logs = [log_weights(a_c), log_weights(a)]
-    b_logs = [log_weights(b_c), log_weights(b)]
+    la_c, la, lb_c, lb = log_weights_many([a_c, a, b_c, b])
+    a_logs, b_logs = [la_c, la], [lb_c, lb]
     if debias:
         C_xxs = [(x_c, x_c.detach(), ranges_x, ranges_x, None), (x, x.detach(), None, None, None)]
         C_yys = [(y_c, y_c.detach(), ranges_y, ranges_y, None), (y, y.detach(), None, None, None)]
@@ -550,6 +562,6 @@ def sinkhorn_multiscale(
     if potentials:  # undo the cluster sort
         F_x, G_y = cost
         f_x, g_y = F_x.clone(), G_y.clone()
-        f_x[perm_x], g_y[perm_y] = F_x, G_y
+        f_x[perm_x.long()], g_y[perm_y.long()] = F_x, G_y
         return f_x, g_y
     return cost

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 111 /* 0.1.11 */
+#define GLHIP_VERSION 112 /* 0.1.11 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -88,6 +88,7 @@ extern "C" {
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
  *   GLHIP_ITER4_PRE_MIN = <p> glhip_sinkhorn_iter4 pre-packs the columns of its problems from <p> pairs per launch on (default 1e8)
+ *   GLHIP_ITER4_SPLITS = <n>  glhip_sinkhorn_iter4 / _extrapolate4, D <= 3, p = 2: column splits per problem instead of the size rule
  *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
  *                             on explicit differences (default 2^-8; 1e30 = every pair, used by the tests to check the register
  *                             <-> column map; 0 = none)
@@ -177,6 +178,24 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
                          float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
                          int B, int N, int M, int D, float eps, float damping, int p, int in_dtype, int first,
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * The coarse-to-fine jump of the two-scale loop in ONE launch (+ one merge launch): the four extrapolations of
+ * sinkhorn_divergence.py:590-599, each `extrapolate_samples` (sinkhorn_samples.py:533-544) — one soft-min of the FINE points against
+ * a COARSE measure:
+ *   f_ba'(x_i) = damping * softmin(eps, C(x_i, yc_j), b_log_c + g_ab / eps)    g_ab'(y_i) = damping * softmin(eps, C(y_i, xc_j), a_log_c + f_ba / eps)
+ *   f_aa'(x_i) = damping * softmin(eps, C(x_i, xc_j), a_log_c + f_aa / eps)    g_bb'(y_i) = damping * softmin(eps, C(y_i, yc_j), b_log_c + g_bb / eps)
+ * x (B,N,D), y (B,M,D): the fine clouds; xc (B,Nc,D), yc (B,Mc,D): the coarse ones (centroids), with their log-weights a_log_c (B,Nc),
+ * b_log_c (B,Mc) and potentials f_ba, f_aa (B,Nc), g_ab, g_bb (B,Mc); outputs (B,N) / (B,M), all fp32.  f_aa / g_bb and their outputs
+ * may be NULL together.  Same kernels, flags, limits (dense, D <= 16, p = 1 or 2) and error behaviour as glhip_sinkhorn_iter4, of which
+ * this is the rows != columns form; replaces four glhip_softmin_fwd launches and their 12 elementwise torch kernels per jump.
+ * Workspace: 4 * glhip_workspace_bytes(B, L, L, D, 0) with L = max(N, M, Nc, Mc).
+ */
+int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, const void* yc, const float* a_log_c, const float* b_log_c,
+                                const float* f_ba, const float* g_ab, const float* f_aa, const float* g_bb,
+                                float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
+                                int B, int N, int M, int Nc, int Mc, int D, float eps, float damping, int p, int in_dtype,
+                                void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * Log-sum-exp along the lines of a regular grid — the separable soft-min of the reference's image / volume path

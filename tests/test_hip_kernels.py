@@ -542,6 +542,49 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl, p):
     assert rc == -1 and b"alias" in lib.glhip_last_error()
 
 
+@pytest.mark.parametrize("fl", [0, hip.FLAG_F16X2], ids=["bf16x3", "f16x2"])
+@pytest.mark.parametrize("N,M,Nc,Mc,D,B", [(3000, 2500, 130, 90, 3, None), (257, 700, 33, 64, 2, None), (640, 511, 17, 40, 1, 3),
+                                           (900, 1000, 70, 65, 6, None), (300, 40, 300, 7, 3, None)])
+@pytest.mark.parametrize("debias", [True, False])
+@pytest.mark.parametrize("p", [2, 1])
+def test_extrapolate4_equals_four_softmins(cuda, N, M, Nc, Mc, D, B, debias, fl, p):
+    """glhip_sinkhorn_extrapolate4 (the coarse-to-fine jump as one launch) == the four `extrapolate_samples` soft-mins of the fine
+    points against the coarse measures (sinkhorn_samples.py:533-544) it replaces, and the float64 oracle on the first of them."""
+    if p == 1 and fl:
+        pytest.skip("the f16 x 2 layout is a p = 2 layout")
+    x, y, _ = _clouds(11 + N, N, M, D, B=B)
+    xc, yc, _ = _clouds(12 + Nc, Nc, Mc, D, B=B)
+    rng = np.random.default_rng(8)
+    sh = (lambda n: (n,)) if B is None else (lambda n: (B, n))
+    a_log = np.log(rng.random(sh(Nc)) + 0.1).astype(np.float32)
+    b_log = np.log(rng.random(sh(Mc)) + 0.1).astype(np.float32)
+    b_log[..., 0] = -100000.0         # a massless cluster (sinkhorn_divergence.log_weights)
+    eps, damping = (0.03 if p == 2 else 0.1), 0.8
+    pots_np = [0.1 * rng.standard_normal(sh(n)).astype(np.float32) for n in (Nc, Mc, Nc, Mc)]      # f_ba, g_ab, f_aa, g_bb on the coarse clouds
+    xt, yt, xct, yct, al, bl = (_t(v, cuda) for v in (x, y, xc, yc, a_log, b_log))
+    pots = [_t(v, cuda) for v in pots_np][: 4 if debias else 2]
+    got = hip.sinkhorn_extrapolate4(eps, xt, yt, xct, yct, al, bl, pots, damping, flags=fl, p=p)
+    one = lambda rows, cols, lw, pot: damping * hip.softmin(eps, rows, cols, lw + pot / eps, p=p, flags=fl)     # noqa: E731
+    want = [one(xt, yct, bl, pots[1]), one(yt, xct, al, pots[0])]
+    if debias:
+        want += [one(xt, xct, al, pots[2]), one(yt, yct, bl, pots[3])]
+    assert len(got) == len(want)
+    tol = 2e-6 if p == 2 else 4e-6
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g - w).abs().max().item() < tol
+    first = lambda a: a if B is None else a[0]      # noqa: E731
+    ref = damping * oracle_c.softmin(eps, first(x), first(yc), first(b_log) + first(pots_np[1]) / eps, p)
+    assert np.abs(first(got[0]).cpu().numpy() - ref).max() < 4e-7 * D + 2e-6 * np.abs(ref).max() + (1e-5 if p == 1 else 0)
+    # error paths of the raw entry point: an empty coarse measure, a missing debiasing output
+    lib = hip.load_library()
+    xb, yb, xcb, ycb = (t if B is not None else t[None] for t in (xt, yt, xct, yct))
+    args = lambda nc, out3: (xb.data_ptr(), yb.data_ptr(), xcb.data_ptr(), ycb.data_ptr(), al.data_ptr(), bl.data_ptr(),      # noqa: E731
+                             pots[0].data_ptr(), pots[1].data_ptr(), None, None, got[0].data_ptr(), got[1].data_ptr(), out3, None,
+                             xb.shape[0], N, M, nc, Mc, D, eps, damping, p, 0, None, 0, 0, None)
+    assert lib.glhip_sinkhorn_extrapolate4(*args(0, None)) == -1 and b"empty coarse" in lib.glhip_last_error()
+    assert lib.glhip_sinkhorn_extrapolate4(*args(Nc, got[0].data_ptr())) == -1 and b"go together" in lib.glhip_last_error()
+
+
 @pytest.mark.parametrize("N,M,D,B", [(300, 257, 3, None), (1030, 70_001, 2, None), (257, 300, 1, 3)])
 @pytest.mark.parametrize("p", [2, 1])
 def test_hard_c_transform_vs_numpy(cuda, N, M, D, B, p):
