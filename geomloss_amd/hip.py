@@ -457,7 +457,11 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True, defer=False):
     return finish(read_back(count)[0])      # the one host round trip
 
 
-_RANGES_WORST_CASE_MAX = 1 << 20     # intervals: up to here the worst-case buffers (2 x 8 MB) are cheaper than a host round trip
+# intervals: up to here the worst-case buffers (2 x 32 MB of address space the kernels touch the used part of) are cheaper than the
+# counting pass (two more launches of 25 us per pattern) and its host round trip.  The ~2000 x 2000 clusters of the reference's
+# voxel rule need 2e6: with 2^20 every pattern of a two-scale loss was counted first — three synchronisations and 0.3 ms of a
+# 6.2-ms loss at N = 1e5 (round 5).
+_RANGES_WORST_CASE_MAX = 1 << 22
 
 
 def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
