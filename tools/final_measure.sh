@@ -37,6 +37,7 @@ leg profile_kernels - 900 bash tools/profile_kernels.sh $TAG            # kernel
 leg trace_all - 900 bash tools/trace_all.sh                             # per-config kernel traces
 leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_report.py
 leg fuzz gpurun_out/fuzz.txt 200 python tools/fuzz_kernels.py 600 3
+leg fuzz_highd gpurun_out/fuzz_highd.txt 200 python tools/fuzz_highd.py 300 3
 leg small_probe gpurun_out/small_probe.txt 200 python tools/small_probe.py
 leg probe_shards gpurun_out/probe_shards.txt 200 python tools/probe_shards.py --calls 200
 leg probe_f16x2 gpurun_out/probe_f16x2.txt 400 python tools/probe_f16x2.py --dims 3,4,8,12,16
