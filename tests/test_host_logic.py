@@ -102,6 +102,76 @@ def test_sinkhorn_loop_with_an_iter4_hook_matches_the_plain_loop():
             assert (u is None and v is None) or torch.allclose(u, v, atol=1e-6)
 
 
+def test_sinkhorn_loop_with_an_extrapolation_hook_matches_the_plain_two_level_loop():
+    """`extrapolate.all4` (the coarse-to-fine jump of every potential as one call) is semantically the four `extrapolate` calls; a
+    hook that answers None leaves them in place; and after a jump that follows the LAST iteration (the differentiable step) the
+    hook is not asked."""
+    from functools import partial
+
+    from geomloss_amd.sinkhorn_divergence import epsilon_schedule, log_weights_many, sinkhorn_loop
+    from geomloss_amd.sinkhorn_samples import softmin_tensorized
+    from geomloss_amd.utils import squared_distances
+
+    torch.manual_seed(1)
+    xc, yc, x, y = torch.rand(1, 7, 2), torch.rand(1, 9, 2), torch.rand(1, 40, 2), torch.rand(1, 50, 2)
+    ws = [torch.full((1, n), 1.0 / n) for n in (7, 40, 9, 50)]
+    la_c, la, lb_c, lb = log_weights_many(ws)
+    C = lambda u, v: squared_distances(u, v) / 2  # noqa: E731
+    # cost objects: (matrix, rows, columns) so that an extrapolation can build the fine-rows x coarse-columns matrix
+    obj = lambda u, v: (C(u, v), u, v)  # noqa: E731
+    softmin = lambda eps, Cm, h: softmin_tensorized(eps, Cm[0], h)  # noqa: E731
+
+    def extrapolate(f_ba, g_ab, eps, damping, C_xy, b_log, C_xy_fine):
+        return damping * softmin_tensorized(eps, C(C_xy_fine[1], C_xy[2]), b_log + g_ab / eps)
+
+    calls = []
+
+    def all4(answer, pots, eps, damping, C_xy, C_yx, a_log, b_log, C_xy_fine, C_yx_fine, debias):
+        calls.append(torch.is_grad_enabled())
+        if not answer:
+            return None
+        out = [extrapolate(pots[0], pots[1], eps, damping, C_xy, b_log, C_xy_fine), extrapolate(pots[1], pots[0], eps, damping, C_yx, a_log, C_yx_fine)]
+        if debias:
+            out += [extrapolate(pots[2], pots[2], eps, damping, (None, C_xy[1], C_xy[1]), a_log, C_xy_fine),
+                    extrapolate(pots[3], pots[3], eps, damping, (None, C_yx[1], C_yx[1]), b_log, C_yx_fine)]
+        return tuple(out)
+
+    eps_list = epsilon_schedule(2, 1.5, 0.1, 0.6)
+    for debias in (True, False):
+        args = ([la_c, la], [lb_c, lb], [obj(xc, xc), obj(x, x)] if debias else None, [obj(yc, yc), obj(y, y)] if debias else None,
+                [obj(xc, yc), obj(x, y)], [obj(yc, xc), obj(y, x)], eps_list, 0.7)
+        kw = dict(kernel_truncation=lambda C_xy, C_yx, C_xy_, C_yx_, *a, **k: (C_xy_, C_yx_), debias=debias)
+        plain = sinkhorn_loop(softmin, *args, jumps=[3], extrapolate=extrapolate, **kw)
+        for answer in (True, False):
+            hooked = partial(extrapolate)
+            hooked.all4 = partial(all4, answer)
+            calls.clear()
+            got = sinkhorn_loop(softmin, *args, jumps=[3], extrapolate=hooked, **kw)
+            assert calls == [False]          # asked once, with autograd off
+            for u, v in zip(plain, got):
+                assert (u is None and v is None) or torch.allclose(u, v, atol=1e-6)
+        hooked = partial(extrapolate)
+        hooked.all4 = partial(all4, True)
+        calls.clear()
+        sinkhorn_loop(softmin, *args, jumps=[len(eps_list) - 1], extrapolate=hooked, **kw)
+        assert calls == []               # the jump after the last iteration is the differentiable step: four plain calls
+
+
+def test_log_weights_many_and_uniform_weights_are_the_one_by_one_values():
+    from geomloss_amd.samples_loss import _uniform_weight
+    ws = [torch.tensor([0.5, 0.0, -1.0, 1e-45, 3.0]), torch.rand(7), torch.zeros(3)]
+    for got, w in zip(sd.log_weights_many(ws), ws):
+        ref = w.log()
+        ref[w <= 0] = -100000.0       # the reference's masked assignment (sinkhorn_divergence.py:61-65)
+        assert torch.equal(got, ref) and torch.equal(sd.log_weights(w), ref)
+    for dt in (torch.float32, torch.bfloat16, torch.float16, torch.float64):
+        for N in (3, 7, 1000, 999983, 16777217):
+            assert torch.equal(torch.full((4,), _uniform_weight(N, dt), dtype=dt), torch.ones(4, dtype=dt) / N)
+    x = torch.rand(2, 5, 3, dtype=torch.float64)
+    w = SamplesLoss("sinkhorn", backend="tensorized").generate_weights(x)
+    assert w.shape == (2, 5) and w.dtype == torch.float64 and torch.equal(w, torch.ones(2, 5, dtype=torch.float64) / 5)
+
+
 def test_sinkhorn_loop_leaves_grad_enabled():
     x, y = torch.rand(20, 2), torch.rand(30, 2)
     with torch.no_grad():
