@@ -1,5 +1,5 @@
 // glhip_api.hip — C-ABI of libgeomloss_hip.so (include/glhip.h), part 1: version / errors / scratch size and the soft-min FORWARD family
-// (glhip_softmin_fwd, glhip_sinkhorn_step, glhip_sinkhorn_iter4, glhip_sinkhorn_extrapolate4).  gfx950 only.
+// (glhip_softmin_fwd, glhip_sinkhorn_step, glhip_sinkhorn_iter4, glhip_sinkhorn_anneal, glhip_sinkhorn_extrapolate4).  gfx950 only.
 #include "glhip_launch.h"
 
 namespace glhip {
@@ -145,6 +145,47 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
              ? iter4_typed<float>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st)
              : iter4_typed<bf16_t>(x, y, a_log, b_log, f_ba, g_ab, f_aa, g_bb, f_ba_out, g_ab_out, f_aa_out, g_bb_out, B, N, M, D, eps, damping, p, first, sc, st);
     return rc ? rc : check_launch("glhip_sinkhorn_iter4");
+}
+
+int glhip_sinkhorn_anneal(const void* x, const void* y, const float* a_log, const float* b_log, float* const* set0, float* const* set1,
+                          int B, int N, int M, int D, const float* eps, const float* damping, int n_eps, int p, int in_dtype,
+                          void* workspace, size_t workspace_bytes, int flags, float f16x2_min_eps, void* stream) {
+    const char* fn = "glhip_sinkhorn_anneal";
+    int rc = check_common(fn, x, y, b_log, B, N, M, D, in_dtype, nullptr, nullptr, nullptr, 0);
+    if (rc) return rc;
+    if ((p != 1 && p != 2) || D > kXdMaxD) return fail(GLHIP_EUNSUPPORTED, "%s: only p = 1, 2 and D <= 16 (got p = %d, D = %d)", fn, p, D);
+    if (flags & (GLHIP_FLAG_DIRECT | GLHIP_FLAG_NO_MFMA | GLHIP_FLAG_F32_MFMA | GLHIP_FLAG_XDL16))
+        return fail(GLHIP_EUNSUPPORTED, "%s: runs on the default 32x32x16 kernel only (flags = %d)", fn, flags);
+    if (n_eps < 1 || !eps || !damping) return fail(GLHIP_EINVAL, "%s: needs n_eps >= 1 temperatures and dampings (n_eps = %d)", fn, n_eps);
+    if (B == 0 || N == 0 || M == 0) return GLHIP_OK;
+    if (!a_log || !set0 || !set1) return fail(GLHIP_EINVAL, "%s: NULL a_log / set0 / set1", fn);
+    float* const* sets[2] = {set0, set1};
+    const bool debias = set0[2] != nullptr;
+    for (int s = 0; s < 2; ++s) {
+        if (!sets[s][0] || !sets[s][1]) return fail(GLHIP_EINVAL, "%s: NULL f_ba / g_ab buffer in set%d", fn, s);
+        if ((sets[s][2] != nullptr) != debias || (sets[s][3] != nullptr) != debias)
+            return fail(GLHIP_EINVAL, "%s: the f_aa / g_bb buffers go together, in both sets or in neither", fn);
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int j = i + 1; j < 8; ++j)
+            if (sets[i / 4][i % 4] && sets[i / 4][i % 4] == sets[j / 4][j % 4])
+                return fail(GLHIP_EINVAL, "%s: a buffer appears twice in set0 / set1 (updates are simultaneous)", fn);
+    for (int i = 0; i < n_eps; ++i)
+        if (!(eps[i] > 0.f)) return fail(GLHIP_EINVAL, "%s: eps[%d] must be > 0", fn, i);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto one = [&](int i, int first, float* const* src, float* const* dst) {
+        int fl = flags & ~GLHIP_FLAG_PREPACK;
+        if (!(eps[i] >= f16x2_min_eps)) fl &= ~GLHIP_FLAG_F16X2;
+        const Scratch sc = make_scratch(workspace, workspace_bytes, fl, 0, N);
+        const float* s0 = src ? src[0] : nullptr; const float* s1 = src ? src[1] : nullptr;
+        const float* s2 = src ? src[2] : nullptr; const float* s3 = src ? src[3] : nullptr;
+        return (in_dtype == GLHIP_F32)
+                   ? iter4_typed<float>(x, y, a_log, b_log, s0, s1, s2, s3, dst[0], dst[1], dst[2], dst[3], B, N, M, D, eps[i], damping[i], p, first, sc, st)
+                   : iter4_typed<bf16_t>(x, y, a_log, b_log, s0, s1, s2, s3, dst[0], dst[1], dst[2], dst[3], B, N, M, D, eps[i], damping[i], p, first, sc, st);
+    };
+    rc = one(0, 1, nullptr, set0);      // initial potentials at the first temperature
+    for (int i = 0; i < n_eps && !rc; ++i) rc = one(i, 0, sets[i % 2], sets[(i + 1) % 2]);
+    return rc ? rc : check_launch(fn);
 }
 
 int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, const void* yc, const float* a_log_c, const float* b_log_c,

@@ -676,6 +676,13 @@ SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* 
 }
 
 // glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
+template <typename T>
+static inline int maxM_all(const SoftminMulti<T>& m) {
+    int v = 0;
+    for (int k = 0; k < m.count; ++k) v = m.M[k] > v ? m.M[k] : v;
+    return v;
+}
+
 template <int D, typename T, int L = XL_BF16X3>
 void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) {
     constexpr int NR = X32Layout<L>::NR;
@@ -695,6 +702,9 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     // ... with at least 3 column tiles per split: a 128-row workgroup that runs one tile of 512 columns is mostly prologue and
     // epilogue (N = M = 1e4, 19 splits by the rule: 64 us per iteration; 6: 57 us; 2e4: 173 -> 166 us; 5e3 and 3e4: unchanged)
     if (minM >= 3072 && minM / sp.n_splits < 1536) sp.n_splits = minM / 1536;
+    // ... and none on tiny unbatched problems: the launch takes as long either way (N = M = 2000: 17.8 us with 3 splits + merge, 18.1 us
+    // with one), and a loop of such launches is bound by the host's launch rate — the merge kernel is one launch in three
+    if (B == 1 && (double)maxN * maxM_all(m) <= 5e6) sp.n_splits = 1;
     static const int force_splits = getenv("GLHIP_ITER4_SPLITS") ? atoi(getenv("GLHIP_ITER4_SPLITS")) : 0;   // tuning knob
     if (force_splits > 0 && sc.allow_split && fit >= force_splits && minM / force_splits >= 64) sp.n_splits = force_splits;
     sp.workspace = static_cast<float*>(sc.ws);

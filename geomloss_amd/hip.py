@@ -40,6 +40,7 @@ SIGNATURES = {
                                      _c_int, _c_int] + _RANGES + _TAIL),
     "glhip_sinkhorn_iter4": (_c_int, [_vp] * 12 + [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int, _c_int]
                              + _TAIL),
+    "glhip_sinkhorn_anneal": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _c_int, _c_float, _vp]),
     "glhip_sinkhorn_extrapolate4": (_c_int, [_vp] * 14 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_int] + _TAIL),
     "glhip_softmin_bwd_x": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
                                      _c_int] + _RANGES + _TAIL),
@@ -836,6 +837,31 @@ class Iter4Plan:
                                            self.flags | self.extra_flags, stream)
         _check(rc, self.lib)
         return tuple(t.view(sh) for t, sh in zip(outs, self.shapes))
+
+
+    def anneal(self, eps_list, dampings, f16x2_min_eps=float("inf")):
+        """The initialisation at ``eps_list[0]`` and one averaged iteration per temperature, queued by ONE library call
+        (``glhip_sinkhorn_anneal``) into the plan's two buffer sets.  Returns ``(final potentials, inputs of the last iteration)``,
+        both shaped like the log-weights; the next :meth:`run` writes over the latter.  GLHIP_FLAG_F16X2 (with the plan's other
+        flags) applies to the temperatures >= ``f16x2_min_eps``."""
+        B, N, M, D = self.dims
+        n = len(eps_list)
+        ptrs = ctypes.c_void_p * 4
+        sets = [ptrs(*([t.data_ptr() for t in bufs] + [None] * (4 - len(bufs)))) for bufs in self.sets]
+        farr = ctypes.c_float * n
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        flags, min_eps = self.flags, min(float(f16x2_min_eps), 3.0e38)
+        if flags & FLAG_F16X2:           # forced for every launch through the environment (GEOMLOSS_HIP_FLAGS)
+            min_eps = 0.0
+        elif min_eps < 3.0e38:
+            flags |= FLAG_F16X2
+        rc = self.lib.glhip_sinkhorn_anneal(*self.fixed, sets[0], sets[1], B, N, M, D, farr(*[float(e) for e in eps_list]),
+                                            farr(*[float(d) for d in dampings]), n, self.p, self.dtype,
+                                            None if self.ws is None else self.ws.data_ptr(), self.nbytes, flags, min_eps, stream)
+        _check(rc, self.lib)
+        self.turn = (n + 1) % 2          # the set the final potentials are NOT in
+        view = lambda bufs: tuple(t.view(sh) for t, sh in zip(bufs, self.shapes))      # noqa: E731
+        return view(self.sets[n % 2]), view(self.sets[(n + 1) % 2])
 
 
 class _Last4(torch.autograd.Function):

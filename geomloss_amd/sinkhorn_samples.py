@@ -210,6 +210,18 @@ class _HipSoftmin:
         plan.extra_flags = self._flags(eps)
         return plan.run(eps, damping, pots)
 
+    def anneal(self, eps_list, dampings, C_xy, a_log, b_log, debias):
+        """The initialisation and all the iterations of a level queued by one library call (``glhip_sinkhorn_anneal``), or None where
+        :meth:`iter4` does not apply (see _iter4_plan) or GEOMLOSS_HIP_ANNEAL=0.  Returns (final potentials, inputs of the last
+        iteration).  Same launches as one :meth:`iter4` call per temperature — the f16 x 2 layout from the same temperature on —
+        without the Python interpreter between them: what bounds a loop on a few thousand points."""
+        if not _anneal_in_library:
+            return None
+        plan = self._iter4_plan(C_xy, a_log, b_log, debias, create=True)
+        if plan is None:
+            return None
+        return plan.anneal(eps_list, dampings, self.h2_min_eps)
+
     def extrapolate4(self, pots, eps, damping, C_xy, C_yx, a_log, b_log, C_xy_fine, C_yx_fine, debias):
         """The coarse-to-fine jump of every potential as one launch (``glhip_sinkhorn_extrapolate4``), or None where the fused
         iterations do not apply either (D > 16, float64 clouds, a kernel-selection flag in the environment, fusion switched off).
@@ -237,6 +249,7 @@ class _HipSoftmin:
 # kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
 _F16X2 = os.environ.get("GEOMLOSS_HIP_F16X2", "1") != "0"      # f16 x 2 exponents where the temperature allows (_HipSoftmin.set_range)
+_anneal_in_library = os.environ.get("GEOMLOSS_HIP_ANNEAL", "1") != "0"   # the iterations of a level queued by one library call (A/B knob)
 _fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
 # ... up to this many pairs per soft-min; bigger problems fill the GPU with one soft-min per launch (pre-packed columns, XCD grids)
 _ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "4e9"))   # measured: B x 4096^2 with B = 32..128 and N = 3e4 gain 5-13 %, 7e4+ lose

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 112 /* 0.1.11 */
+#define GLHIP_VERSION 113 /* 0.1.11 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -178,6 +178,24 @@ int glhip_sinkhorn_iter4(const void* x, const void* y, const float* a_log, const
                          float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
                          int B, int N, int M, int D, float eps, float damping, int p, int in_dtype, int first,
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * A whole run of the symmetric eps-scaling loop, queued by ONE call: the initialisation at eps[0] (sinkhorn_divergence.py:461-465)
+ * followed by one averaged iteration per temperature eps[0..n_eps-1] (:468-493), each a glhip_sinkhorn_iter4 launch (+ merge) with
+ * its own temperature and damping[i] — what the Python loop queues with one host-side call per iteration, minus the interpreter
+ * between the launches (loops on a few thousand points are bound by the host's launch rate: N = 2000, 10 temperatures: 0.46 -> 0.36 ms).
+ * The temperatures are plain host arrays, computed after whatever the caller measured (a diameter), so nothing is baked in.
+ *   set0, set1: two sets of output buffers {f_ba (B,N), g_ab (B,M), f_aa (B,N), g_bb (B,M)} (the last two NULL in both sets without
+ *   debiasing).  The initial potentials go to set0, iteration i reads set[i % 2] and writes set[(i + 1) % 2]: on return (queued) the
+ *   final potentials are in set[n_eps % 2] and the inputs of the last iteration in the other one.  No buffer may appear twice.
+ *   flags: as glhip_sinkhorn_iter4, with GLHIP_FLAG_F16X2 applied to the iterations whose eps[i] >= f16x2_min_eps only (the caller's
+ *   range vouching is per temperature; pass 0 to apply it everywhere, a huge value or no flag for never).
+ * Dense, D <= 16, p = 1 or 2, n_eps >= 1; workspace as glhip_sinkhorn_iter4.  Used for single-scale losses and for the coarse level of
+ * the two-scale ones (everything up to the jump).
+ */
+int glhip_sinkhorn_anneal(const void* x, const void* y, const float* a_log, const float* b_log, float* const* set0, float* const* set1,
+                          int B, int N, int M, int D, const float* eps, const float* damping, int n_eps, int p, int in_dtype,
+                          void* workspace, size_t workspace_bytes, int flags, float f16x2_min_eps, void* stream);
 
 /*
  * The coarse-to-fine jump of the two-scale loop in ONE launch (+ one merge launch): the four extrapolations of

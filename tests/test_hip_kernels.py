@@ -9,6 +9,8 @@ Both are far inside the 1e-4 relative budget BASELINE.json states for the loss; 
 tests/test_samples_loss_gpu.py.
 """
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -540,6 +542,53 @@ def test_iter4_equals_four_fused_steps(cuda, N, M, D, B, debias, fl, p):
                                   None, None, f_ba.data_ptr(), g_ab.data_ptr(), None, None, xb.shape[0], N, M, D, eps, damping,
                                   2, 0, 0, None, 0, 0, None)
     assert rc == -1 and b"alias" in lib.glhip_last_error()
+
+
+@pytest.mark.parametrize("N,M,D,B,p", [(700, 900, 3, None, 2), (257, 255, 1, 3, 2), (600, 700, 5, None, 2), (500, 300, 3, None, 1), (300, 400, 9, 2, 1)])
+@pytest.mark.parametrize("debias", [True, False])
+def test_anneal_equals_one_iter4_call_per_temperature(cuda, N, M, D, B, p, debias):
+    """glhip_sinkhorn_anneal == the initialisation and one glhip_sinkhorn_iter4 call per temperature (bit for bit: same launches),
+    the f16 x 2 layout switched on from the temperature given; final potentials and the inputs of the last iteration; error paths."""
+    x, y, _ = _clouds(31 + N, N, M, D, B=B)
+    rng = np.random.default_rng(9)
+    sh = (lambda n: (n,)) if B is None else (lambda n: (B, n))
+    al = _t(np.log(rng.random(sh(N)) + 0.1).astype(np.float32), cuda)
+    bl = _t(np.log(rng.random(sh(M)) + 0.1).astype(np.float32), cuda)
+    xt, yt = _t(x, cuda), _t(y, cuda)
+    eps_list = [2.0, 2.0, 0.8, 0.3, 0.1, 0.04, 0.02]
+    dampings = [1.0 / (1.0 + e / 0.7) for e in eps_list]
+    min_eps = 0.2 if p == 2 else float("inf")         # f16 x 2 for the first four temperatures only (p = 2)
+    ref_plan = hip.Iter4Plan(xt, yt, al, bl, debias, p=p)
+    flag = lambda e: hip.FLAG_F16X2 if e >= min_eps else 0      # noqa: E731
+    ref_plan.extra_flags = flag(eps_list[0])
+    pots = ref_plan.run(eps_list[0], dampings[0], None)
+    before = None
+    for e, d in zip(eps_list, dampings):
+        before = tuple(t.clone() for t in pots)
+        ref_plan.extra_flags = flag(e)
+        pots = tuple(t.clone() for t in ref_plan.run(e, d, pots))
+    plan = hip.Iter4Plan(xt, yt, al, bl, debias, p=p)
+    new, old = plan.anneal(eps_list, dampings, min_eps)
+    assert len(new) == (4 if debias else 2)
+    for got, want in zip(new + old, pots + before):
+        assert got.shape == want.shape and torch.equal(got, want)
+    # the plan goes on where the library call stopped: one more iteration from Python reads `new` and leaves it intact
+    more = plan.run(0.02, 1.0, new)
+    ref_plan.extra_flags = 0
+    for got, want in zip(more, ref_plan.run(0.02, 1.0, pots)):
+        assert torch.equal(got, want)
+    for got, want in zip(new, pots):
+        assert torch.equal(got, want)
+    # error paths: a buffer that appears twice, a non-positive temperature
+    lib = hip.load_library()
+    ptrs = ctypes.c_void_p * 4
+    bufs = [t.data_ptr() for t in plan.sets[0]] + [None] * (4 - len(plan.sets[0]))
+    farr = ctypes.c_float * 2
+    call = lambda s0, s1, eps: lib.glhip_sinkhorn_anneal(*plan.fixed, ptrs(*s0), ptrs(*s1), *plan.dims, farr(*eps), farr(1.0, 1.0), 2, p,      # noqa: E731
+                                                         plan.dtype, None, 0, 0, 0.0, None)
+    assert call(bufs, bufs, (1.0, 0.5)) == -1 and b"twice" in lib.glhip_last_error()
+    other = [t.data_ptr() for t in plan.sets[1]] + [None] * (4 - len(plan.sets[1]))
+    assert call(bufs, other, (1.0, 0.0)) == -1 and b"eps[1]" in lib.glhip_last_error()
 
 
 @pytest.mark.parametrize("fl", [0, hip.FLAG_F16X2], ids=["bf16x3", "f16x2"])

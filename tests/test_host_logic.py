@@ -157,6 +157,64 @@ def test_sinkhorn_loop_with_an_extrapolation_hook_matches_the_plain_two_level_lo
         assert calls == []               # the jump after the last iteration is the differentiable step: four plain calls
 
 
+@pytest.mark.parametrize("jumps", [[], [3]])
+def test_sinkhorn_loop_with_an_anneal_hook_matches_the_plain_loop(jumps):
+    """`softmin.anneal` (the initialisation and every iteration of the first level in one call) is semantically those iterations:
+    a single-scale loop hands it the whole schedule, a two-level one the temperatures up to its jump; None leaves the loop alone."""
+    from geomloss_amd.sinkhorn_divergence import epsilon_schedule, log_weights_many, sinkhorn_loop
+    from geomloss_amd.sinkhorn_samples import softmin_tensorized
+    from geomloss_amd.utils import squared_distances
+
+    torch.manual_seed(2)
+    xc, yc, x, y = torch.rand(1, 7, 2), torch.rand(1, 9, 2), torch.rand(1, 40, 2), torch.rand(1, 50, 2)
+    la_c, la, lb_c, lb = log_weights_many([torch.full((1, n), 1.0 / n) for n in (7, 40, 9, 50)])
+    C = lambda u, v: squared_distances(u, v) / 2  # noqa: E731
+    obj = lambda u, v: (C(u, v), u, v)  # noqa: E731
+    eps_list = epsilon_schedule(2, 1.5, 0.1, 0.6)
+
+    def extrapolate(f_ba, g_ab, eps, damping, C_xy, b_log, C_xy_fine):
+        return damping * softmin_tensorized(eps, C(C_xy_fine[1], C_xy[2]), b_log + g_ab / eps)
+
+    class Soft:
+        seen = None
+
+        def __init__(self, answer):
+            self.answer = answer
+
+        def __call__(self, eps, Cm, h):
+            return softmin_tensorized(eps, Cm[0], h)
+
+        def anneal(self, eps_l, dampings, C_xy, a_log, b_log, debias):
+            Soft.seen = (list(eps_l), list(dampings))
+            if not self.answer:
+                return None
+            xs, ys = C_xy[1], C_xy[2]
+            costs = [(C(xs, ys), b_log), (C(ys, xs), a_log)] + ([(C(xs, xs), a_log), (C(ys, ys), b_log)] if debias else [])
+            src = [1, 0, 2, 3]      # the potential each update reads: g_ab for f_ba, f_ba for g_ab, its own for the debiasing pair
+            pots = [dampings[0] * softmin_tensorized(eps_l[0], Cm, lw) for Cm, lw in costs]
+            old = pots
+            for e, d in zip(eps_l, dampings):
+                old = pots
+                pots = [0.5 * (old[k] + d * softmin_tensorized(e, costs[k][0], costs[k][1] + old[src[k]] / e)) for k in range(len(costs))]
+            return tuple(pots), tuple(old)
+
+    for debias in (True, False):
+        if jumps:
+            args = ([la_c, la], [lb_c, lb], [obj(xc, xc), obj(x, x)] if debias else None, [obj(yc, yc), obj(y, y)] if debias else None,
+                    [obj(xc, yc), obj(x, y)], [obj(yc, xc), obj(y, x)], eps_list, 0.7)
+            kw = dict(jumps=jumps, extrapolate=extrapolate, kernel_truncation=lambda C_xy, C_yx, C_xy_, C_yx_, *a, **k: (C_xy_, C_yx_))
+        else:
+            args = (la, lb, obj(x, x) if debias else None, obj(y, y) if debias else None, obj(x, y), obj(y, x), eps_list, 0.7)
+            kw = {}
+        plain = sinkhorn_loop(lambda eps, Cm, h: softmin_tensorized(eps, Cm[0], h), *args, debias=debias, **kw)
+        for answer in (True, False):
+            got = sinkhorn_loop(Soft(answer), *args, debias=debias, **kw)
+            want = eps_list[: jumps[0] + 1] if jumps else eps_list
+            assert Soft.seen[0] == list(want) and Soft.seen[1] == [sd.dampening(e, 0.7) for e in want]
+            for u, v in zip(plain, got):
+                assert (u is None and v is None) or torch.allclose(u, v, atol=1e-6)
+
+
 def test_log_weights_many_and_uniform_weights_are_the_one_by_one_values():
     from geomloss_amd.samples_loss import _uniform_weight
     ws = [torch.tensor([0.5, 0.0, -1.0, 1e-45, 3.0]), torch.rand(7), torch.zeros(3)]

@@ -187,6 +187,36 @@ def test_fused_iterations_reproduce_the_per_softmin_loop(cuda, kw):
         assert (g1 - g0).abs().max().item() <= gtol * g0.abs().max().item() + 1e-9
 
 
+@pytest.mark.parametrize("backend,D,p,kw", [("online", 3, 2, dict()), ("online", 3, 2, dict(debias=False, reach=0.5)), ("online", 3, 1, dict()),
+                                            ("online", 6, 2, dict(potentials=True)), ("multiscale", 3, 2, dict()),
+                                            ("multiscale", 2, 2, dict(reach=0.7))])
+def test_library_side_annealing_is_the_same_loop(cuda, backend, D, p, kw):
+    """glhip_sinkhorn_anneal (every iteration of a level queued by one library call) against one glhip_sinkhorn_iter4 call per
+    temperature from Python: the same launches with the same arguments — identical losses, potentials and gradients, bit for bit;
+    batched bf16 points and a given diameter included."""
+    from geomloss_amd import sinkhorn_samples as ss
+
+    for B, dtype, diameter in ((None, torch.float32, None), (3, torch.bfloat16, 2.0)):
+        if backend == "multiscale" and B is not None:
+            continue
+        L = SamplesLoss("sinkhorn", p=p, blur=0.05, scaling=0.6, backend=backend, diameter=diameter, **kw)
+        torch.manual_seed(6)
+        shp = (lambda n: (n, D)) if B is None else (lambda n: (B, n, D))
+        x = torch.rand(shp(900), device=cuda).to(dtype).requires_grad_(True)
+        y = torch.rand(shp(700), device=cuda).to(dtype)
+        res = {}
+        for on in (True, False):
+            ss._anneal_in_library = on
+            try:
+                out = L(x, y)
+                v = out[0].sum() + out[1].sum() if kw.get("potentials") else out.sum()
+                (g,) = torch.autograd.grad(v, [x])
+                res[on] = (v.detach().clone(), g.clone())
+            finally:
+                ss._anneal_in_library = True
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_bench_sharded_path_two_ranks_on_one_gpu(cuda):
     """`bench.py --gpus 2` — the N > 1 leg the driver launches on a multi-GPU node (BASELINE configs[3] through
     ShardedSamplesLoss) — exercised here with two processes sharing cuda:0 over gloo; its loss must equal the unsharded one."""

@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 n, D = int(float(sys.argv[1])), int(sys.argv[2])
 g = torch.Generator().manual_seed(3)
 x, y = torch.rand(n, D, generator=g).to(dev), torch.rand(n, D, generator=g).to(dev)
-loss = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale", verbose=len(sys.argv) > 3)
+loss = SamplesLoss("sinkhorn", p=2, blur=0.05, backend=os.environ.get("BACKEND", "multiscale"), verbose=len(sys.argv) > 3)      # BACKEND=online: the single-scale loss
 reps, ts = int(os.environ.get("REPS", "3")), []       # REPS=30: the median over many calls (small clouds: +-0.2 ms from call to call)
 for r in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
