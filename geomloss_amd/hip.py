@@ -808,6 +808,7 @@ class Iter4Plan:
                     bufs.append(flat[o:o + B * n].view(B, n))
                     o += B * n
                 self.sets.append(bufs)
+        self.shaped = [tuple(t.view(sh) for t, sh in zip(bufs, self.shapes)) for bufs in self.sets]     # what run / anneal hand out
         self.turn = 0
         self.extra_flags = 0      # per-call flags of the owner (GLHIP_FLAG_F16X2 where the temperature allows: sinkhorn_samples._HipSoftmin)
         self.fixed = (xb.data_ptr(), yb.data_ptr(), self.a_log.data_ptr(), bl.data_ptr())
@@ -817,10 +818,10 @@ class Iter4Plan:
         """pots None: initial potentials.  Otherwise the averaged update, or with ``last`` the plain, non-averaged
         update ``damping * softmin(eps, C, logw + pot/eps)`` written to fresh tensors (the differentiable step)."""
         B, N, M, D = self.dims
-        if last:
-            outs = [torch.empty((B, n), dtype=torch.float32, device=self.device) for n in ((N, M, N, M) if self.debias else (N, M))]
+        if last:      # fresh tensors, in the shapes of the log-weights (same element counts as (B, N) / (B, M))
+            outs = shaped = tuple(torch.empty(sh, dtype=torch.float32, device=self.device) for sh in self.shapes)
         else:
-            outs = self.sets[self.turn]
+            outs, shaped = self.sets[self.turn], self.shaped[self.turn]
             self.turn ^= 1
         if pots is None:
             old = (None, None, None, None)
@@ -836,8 +837,7 @@ class Iter4Plan:
                                            1 if pots is None else (2 if last else 0), None if self.ws is None else self.ws.data_ptr(), self.nbytes,
                                            self.flags | self.extra_flags, stream)
         _check(rc, self.lib)
-        return tuple(t.view(sh) for t, sh in zip(outs, self.shapes))
-
+        return shaped
 
     def anneal(self, eps_list, dampings, f16x2_min_eps=float("inf")):
         """The initialisation at ``eps_list[0]`` and one averaged iteration per temperature, queued by ONE library call
@@ -860,8 +860,7 @@ class Iter4Plan:
                                             None if self.ws is None else self.ws.data_ptr(), self.nbytes, flags, min_eps, stream)
         _check(rc, self.lib)
         self.turn = (n + 1) % 2          # the set the final potentials are NOT in
-        view = lambda bufs: tuple(t.view(sh) for t, sh in zip(bufs, self.shapes))      # noqa: E731
-        return view(self.sets[n % 2]), view(self.sets[(n + 1) % 2])
+        return self.shaped[n % 2], self.shaped[(n + 1) % 2]
 
 
 class _Last4(torch.autograd.Function):
@@ -909,8 +908,9 @@ class _Last4(torch.autograd.Function):
 
 def sinkhorn_last4(plan, x, y, eps, damping, pots):
     """Differentiable last update through an :class:`Iter4Plan`; returns the new potentials shaped like the old ones."""
-    outs = _Last4.apply(x, y, plan, float(eps), float(damping), *pots)
-    return tuple(o.view(sh) for o, sh in zip(outs, plan.shapes))
+    if not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)):      # nothing to differentiate: no autograd node
+        return plan.run(float(eps), float(damping), tuple(p.detach() for p in pots), last=True)
+    return _Last4.apply(x, y, plan, float(eps), float(damping), *pots)        # (Iter4Plan.run hands them out in those shapes)
 
 
 # kernel-selection knobs for A/B runs (SURVEY §5: tuning through the environment only): a GLHIP_FLAG_* bitmask
