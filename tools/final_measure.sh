@@ -11,9 +11,10 @@ STATUS=gpurun_out/final_measure_$TAG.status
 : > $STATUS
 FAIL=0
 
-leg() {   # leg <name> <output file | -> <timeout s> <command...>
+leg() {   # leg <name> <output file | -> <timeout s> <command...>     (SKIP="name name ..." in the environment leaves legs out)
     local name=$1 out=$2 limit=$3
     shift 3
+    case " ${SKIP:-} " in *" $name "*) echo "skipped leg '$name'" >> $STATUS; return;; esac
     if [ "$out" = "-" ]; then
         timeout "$limit" "$@" > /dev/null 2> gpurun_out/$name.err
     else
