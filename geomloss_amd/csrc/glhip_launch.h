@@ -676,6 +676,12 @@ SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* 
 }
 
 // glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
+// rows x columns of one problem up to which an unbatched multi launch runs without column splits (GLHIP_TINY_MULTI_PAIRS: tuning knob)
+static inline double tiny_multi_pairs() {
+    static const double v = getenv("GLHIP_TINY_MULTI_PAIRS") ? atof(getenv("GLHIP_TINY_MULTI_PAIRS")) : 5e6;
+    return v;
+}
+
 template <typename T>
 static inline int maxM_all(const SoftminMulti<T>& m) {
     int v = 0;
@@ -704,7 +710,7 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     if (minM >= 3072 && minM / sp.n_splits < 1536) sp.n_splits = minM / 1536;
     // ... and none on tiny unbatched problems: the launch takes as long either way (N = M = 2000: 17.8 us with 3 splits + merge, 18.1 us
     // with one), and a loop of such launches is bound by the host's launch rate — the merge kernel is one launch in three
-    if (B == 1 && (double)maxN * maxM_all(m) <= 5e6) sp.n_splits = 1;
+    if (B == 1 && (double)maxN * maxM_all(m) <= tiny_multi_pairs()) sp.n_splits = 1;
     static const int force_splits = getenv("GLHIP_ITER4_SPLITS") ? atoi(getenv("GLHIP_ITER4_SPLITS")) : 0;   // tuning knob
     if (force_splits > 0 && sc.allow_split && fit >= force_splits && minM / force_splits >= 64) sp.n_splits = force_splits;
     sp.workspace = static_cast<float*>(sc.ws);
@@ -762,6 +768,9 @@ void launch_iter4_xd(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t s
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    // host-bound loops: no merge launch (launch_iter4) — here only up to ~1000 x 1000: the heavier exponent chain of D > 3 wants its
+    // workgroups (N = M = 2000, D = 4 / 16: 0.35 / 0.42 ms per loss with 3 splits, 0.43 / 0.58 ms with one; N = 1000, D = 4: 0.38 -> 0.35 ms)
+    if (B == 1 && (double)maxN * maxM_all(m) <= 0.3 * tiny_multi_pairs()) sp.n_splits = 1;
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;   // per problem, set in the kernels
     sp.xcd_grid_x = 0;
@@ -797,6 +806,7 @@ void launch_iter4_dist(SoftminMulti<T>& m, int B, float eps, const Scratch& sc, 
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
+    // (no tiny-launch rule here: p = 1 at N = M = 2000 runs 0.54 ms per loss with 3 splits, 0.84 ms with one)
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;
     sp.xcd_grid_x = 0;
