@@ -294,8 +294,7 @@ def sinkhorn_extrapolate4_raw(x, y, xc, yc, a_log_c, b_log_c, pots, eps, damping
     old = [t.data_ptr() for t in pots] + [None] * (4 - len(pots))
     new = [t.data_ptr() for t in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
-        L = max(N, M, Nc, Mc)
-        nbytes = 4 * int(lib.glhip_workspace_bytes(B, L, L, D, 0))
+        nbytes = 4 * int(lib.glhip_workspace_bytes(B, max(N, M), max(Nc, Mc), D, 0))     # rows: fine clouds, columns: coarse ones
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         rc = lib.glhip_sinkhorn_extrapolate4(x.data_ptr(), y.data_ptr(), xc.data_ptr(), yc.data_ptr(), a_log_c.data_ptr(), b_log_c.data_ptr(),
                                              *old, *new, B, N, M, Nc, Mc, D, float(eps), float(damping), int(p), _dtype_code(x),

@@ -209,7 +209,8 @@ int glhip_sinkhorn_anneal(const void* x, const void* y, const float* a_log, cons
  * b_log_c (B,Mc) and potentials f_ba, f_aa (B,Nc), g_ab, g_bb (B,Mc); outputs (B,N) / (B,M), all fp32.  f_aa / g_bb and their outputs
  * may be NULL together.  Same kernels, flags, limits (dense, D <= 16, p = 1 or 2) and error behaviour as glhip_sinkhorn_iter4, of which
  * this is the rows != columns form; replaces four glhip_softmin_fwd launches and their 12 elementwise torch kernels per jump.
- * Workspace: 4 * glhip_workspace_bytes(B, L, L, D, 0) with L = max(N, M, Nc, Mc).
+ * Workspace: 4 * glhip_workspace_bytes(B, max(N, M), max(Nc, Mc), D, 0) (rows: the fine clouds, columns: the coarse ones); as with every
+ * entry point a smaller (or NULL) workspace is accepted: fewer column splits, no pre-packed columns, same results up to rounding.
  */
 int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, const void* yc, const float* a_log_c, const float* b_log_c,
                                 const float* f_ba, const float* g_ab, const float* f_aa, const float* g_bb,
