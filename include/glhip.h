@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 113 /* 0.1.11 */
+#define GLHIP_VERSION 113 /* 0.1.13 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
