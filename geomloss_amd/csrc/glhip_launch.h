@@ -768,9 +768,8 @@ void launch_iter4_xd(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t s
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
-    // host-bound loops: no merge launch (launch_iter4) — here only up to ~1000 x 1000: the heavier exponent chain of D > 3 wants its
-    // workgroups (N = M = 2000, D = 4 / 16: 0.35 / 0.42 ms per loss with 3 splits, 0.43 / 0.58 ms with one; N = 1000, D = 4: 0.38 -> 0.35 ms)
-    if (B == 1 && (double)maxN * maxM_all(m) <= 0.3 * tiny_multi_pairs()) sp.n_splits = 1;
+    // (no tiny-launch rule as in launch_iter4: N = M = 2000, D = 4 / 16 run 0.35 / 0.42 ms per loss with 3 splits, 0.43 / 0.58 ms with one)
+    // (and more splits than the rule's do not pay either: 7 splits of 256 columns at N = M = 2000 measure like 3 — these loops are host-bound)
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;   // per problem, set in the kernels
     sp.xcd_grid_x = 0;
@@ -806,7 +805,20 @@ void launch_iter4_dist(SoftminMulti<T>& m, int B, float eps, const Scratch& sc, 
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
-    // (no tiny-launch rule here: p = 1 at N = M = 2000 runs 0.54 ms per loss with 3 splits, 0.84 ms with one)
+    // (no tiny-launch rule here: p = 1 at N = M = 2000 runs 0.54 ms per loss with 3 splits, 0.84 ms with one) — the other way round:
+    // 256-row workgroups of a few thousand points are a handful (N = 1000: 16), so small launches split down to 128 columns
+    // (GLHIP_DIST_MULTI_MIN_COLS) until ~2 workgroups per CU exist
+    {
+        static const int min_cols = getenv("GLHIP_DIST_MULTI_MIN_COLS") ? atoi(getenv("GLHIP_DIST_MULTI_MIN_COLS")) : 128;
+        if (sc.allow_split && min_cols > 0 && row_blocks * sp.n_splits < 512) {
+            long want = (512 + row_blocks - 1) / row_blocks;
+            const long by_cols = minM / min_cols;
+            want = want < by_cols ? want : by_cols;
+            want = want < 32 ? want : 32;
+            want = want < fit ? want : fit;
+            if (want > sp.n_splits) sp.n_splits = (int)want;
+        }
+    }
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;
     sp.xcd_grid_x = 0;

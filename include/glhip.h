@@ -88,6 +88,8 @@ extern "C" {
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
  *   GLHIP_ITER4_PRE_MIN = <p> glhip_sinkhorn_iter4 pre-packs the columns of its problems from <p> pairs per launch on (default 1e8)
+ *   GLHIP_DIST_MULTI_MIN_COLS = <c> p = 1 glhip_sinkhorn_iter4 / _anneal / _extrapolate4: launches with fewer than 512 workgroups split their
+ *                             columns down to <c> per split (default 128; 0: the size rule only)
  *   GLHIP_TINY_MULTI_PAIRS = <p> unbatched glhip_sinkhorn_iter4 / _anneal / _extrapolate4 launches of up to <p> rows x columns per problem run
  *                             without column splits, i.e. without a merge launch (default 5e6; 0: always the size rule)
  *   GLHIP_ITER4_SPLITS = <n>  glhip_sinkhorn_iter4 / _extrapolate4, D <= 3, p = 2: column splits per problem instead of the size rule
