@@ -21,6 +21,15 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
                 nf = nf > nx ? nf : nx;
             }
         }
+        if (n_ranges == 0) {      // small dense launches of the distance kernels split further (dist_small_launch_splits, glhip_launch.h)
+            const long rb = (long)B * ((N + 255) / 256);
+            if (rb * nf < 512) {
+                long want = (512 + rb - 1) / rb;
+                want = want < M / 128 ? want : M / 128;
+                want = want < 32 ? want : 32;
+                nf = nf > want ? nf : (int)want;
+            }
+        }
         // forward partials: 2 floats per row and split; gradient kernels (glhip_wsum_t32.h, 256-row blocks): D + 1
         size_t bytes = (size_t)(nf < 2 ? 0 : nf) * (size_t)B * (size_t)N * 2 * sizeof(float);
         int ng = choose_splits(n_ranges > 0 ? n_ranges : (long)B * ((N + 255) / 256), M, n_ranges, 1L << 30);

@@ -496,6 +496,20 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
 }
 
 // distance reductions for 4 <= D <= 16, dense launches (glhip_dist_xd.h): soft-min p = 1 / fused half-step, laplacian and energy products
+// 256-row workgroups of the distance kernels on a few thousand points are a handful (N = 1000: 4 per problem): launches with fewer than
+// 512 workgroups split their columns down to GLHIP_DIST_MULTI_MIN_COLS (128) per split, up to 32 splits and what the workspace holds
+// (online p = 1 losses at N = 1000 / 2000: 0.53 / 0.49 -> 0.35 / 0.38 ms)
+static inline int dist_small_launch_splits(int n_splits, long row_blocks, int M, long fit, bool allow_split) {
+    static const int min_cols = getenv("GLHIP_DIST_MULTI_MIN_COLS") ? atoi(getenv("GLHIP_DIST_MULTI_MIN_COLS")) : 128;
+    if (!allow_split || min_cols <= 0 || row_blocks * n_splits >= 512) return n_splits;
+    long want = (512 + row_blocks - 1) / row_blocks;
+    const long by_cols = M / min_cols;
+    want = want < by_cols ? want : by_cols;
+    want = want < 32 ? want : 32;
+    want = want < fit ? want : fit;
+    return want > n_splits ? (int)want : n_splits;
+}
+
 template <int MODE, int D, typename T, class MergeOp>
 void launch_dist_xd(const DistParams<T>& prm, const typename MergeOp::Params& mprm, int B, int N, int M, const Scratch& sc, hipStream_t st) {
     constexpr int NW = 8, kRows = NW * 32;
@@ -506,6 +520,7 @@ void launch_dist_xd(const DistParams<T>& prm, const typename MergeOp::Params& mp
     const long fit = sc.ws ? (long)(sc.bytes / per_split) : 0;
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits((long)gx * B, M, 0, fit) : 1;
+    sp.n_splits = dist_small_launch_splits(sp.n_splits, (long)gx * B, M, fit, sc.allow_split);
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = (long)B * N * kPart;
     sp.xcd_grid_x = 0;
@@ -806,19 +821,7 @@ void launch_iter4_dist(SoftminMulti<T>& m, int B, float eps, const Scratch& sc, 
     SplitInfo sp;
     sp.n_splits = (sc.allow_split && fit >= 2) ? choose_splits(row_blocks, minM, 0, fit) : 1;
     // (no tiny-launch rule here: p = 1 at N = M = 2000 runs 0.54 ms per loss with 3 splits, 0.84 ms with one) — the other way round:
-    // 256-row workgroups of a few thousand points are a handful (N = 1000: 16), so small launches split down to 128 columns
-    // (GLHIP_DIST_MULTI_MIN_COLS) until ~2 workgroups per CU exist
-    {
-        static const int min_cols = getenv("GLHIP_DIST_MULTI_MIN_COLS") ? atoi(getenv("GLHIP_DIST_MULTI_MIN_COLS")) : 128;
-        if (sc.allow_split && min_cols > 0 && row_blocks * sp.n_splits < 512) {
-            long want = (512 + row_blocks - 1) / row_blocks;
-            const long by_cols = minM / min_cols;
-            want = want < by_cols ? want : by_cols;
-            want = want < 32 ? want : 32;
-            want = want < fit ? want : fit;
-            if (want > sp.n_splits) sp.n_splits = (int)want;
-        }
-    }
+    sp.n_splits = dist_small_launch_splits(sp.n_splits, row_blocks, minM, fit, sc.allow_split);
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;
     sp.xcd_grid_x = 0;
