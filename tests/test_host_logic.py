@@ -555,6 +555,36 @@ def test_shared_library_exports_every_declared_symbol():
     assert lib.glhip_version() == int(re.search(r"#define GLHIP_VERSION (\d+)", header).group(1))
 
 
+def test_ctypes_signatures_follow_the_header_prototypes():
+    """Every prototype of include/glhip.h against the ctypes signature geomloss_amd/hip.py binds it with: the same number of
+    parameters, and the same kind in every position (pointer / int / long / float / double / size_t) — an argument short or a
+    float where the header says int would be read from the wrong register without any error."""
+    header = open(os.path.join(ROOT, "include", "glhip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|const char\s*\*)\s+(glhip_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert {name for _, name, _ in protos} == set(hip.SIGNATURES)
+    # (long and long long are one 64-bit kind here, as they are one ctypes class on LP64)
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_longlong: "long", ctypes.c_float: "float",
+             ctypes.c_double: "double", ctypes.c_size_t: "size_t", ctypes.c_char_p: "ptr"}
+
+    def kind_of(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "ptr"
+        for word, k in (("size_t", "size_t"), ("long", "long"), ("double", "double"), ("float", "float"), ("int", "int")):
+            if re.search(r"\b" + word + r"\b", param):
+                return k
+        raise AssertionError(f"unrecognised parameter '{param}'")
+
+    for ret, name, params in protos:
+        params = params.strip()
+        want = [] if params in ("", "void") else [kind_of(q) for q in params.split(",")]
+        restype, argtypes = hip.SIGNATURES[name]
+        got = [kinds[t] for t in argtypes]
+        assert got == want, f"{name}: header {want} vs ctypes {got}"
+        assert kinds[restype] == ("ptr" if "char" in ret else ret.strip()), name
+
+
 def test_oracle_is_not_imported_by_the_product():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "geomloss_amd")):
         for f in files:
