@@ -25,11 +25,17 @@ def golden_cases(mid=False):
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
-        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_", "ot_", "reference_")):
-            continue   # special cases, and the grid-path vectors of make_golden_images.py (tests/test_images_*.py)
+        if name in ("cfg1_n2000_d2", "softmin_tensorized") or name.startswith(("images_", "volumes_", "barycenter_", "ot_", "reference_", "multiscale_", "kernel_multiscale_")):
+            continue   # special cases, the grid-path vectors of make_golden_images.py (tests/test_images_*.py), the two-scale runs
         if name not in MID_SIZE:
             out.append(name)
     return out
+
+
+def multiscale_cases(kernels=False):
+    """Runs of the reference's own two-scale drivers (tests/golden/make_golden_multiscale.py)."""
+    pre = "kernel_multiscale_" if kernels else "multiscale_"
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, pre + "*.npz")))
 
 
 def ot_golden_cases():
