@@ -121,10 +121,12 @@ def native_clustering_applies(x, labels=None):
             and x.dtype in (torch.float32, torch.bfloat16) and hip.library_available())
 
 
-def clusterize_device_many(clouds, scale, pre_div=1.0, long_perm=True):
+def clusterize_device_many(clouds, scale, pre_div=1.0, long_perm=True, extent=None):
     """:func:`clusterize_device` for several weighted clouds ``[(a, x), ...]`` with ONE host round trip for all their cluster counts
     (the two measures of a two-scale loss: one synchronisation instead of two).  ``long_perm=False``: the permutations stay int32,
-    as the kernel wrote them, for callers that only index with them now and then (one launch less per cloud)."""
+    as the kernel wrote them, for callers that only index with them now and then (one launch less per cloud).  ``extent``: a list
+    that receives an upper bound of the diagonal of the clouds' joint bounding box (``hip.voxel_extent``: the voxel bounds come
+    back in the same round trip)."""
     from . import hip
     pending = []
     for a, x in clouds:
@@ -133,6 +135,8 @@ def clusterize_device_many(clouds, scale, pre_div=1.0, long_perm=True):
         need_graph = torch.is_grad_enabled() and (x.requires_grad or (a is not None and a.requires_grad))
         pending.append((a, x, need_graph, hip.grid_cluster_raw(xd, ad, scale, pre_div, gather=not need_graph, defer=True)))
     counts = hip.read_back(*[p[3][0] for p in pending])
+    if extent is not None:
+        extent.append(hip.voxel_extent(counts, scale, pre_div))
     out = []
     for (a, x, need_graph, (_, finish)), values in zip(pending, counts):
         perm32, xs, ws, ranges, cents, w_c = finish(values)

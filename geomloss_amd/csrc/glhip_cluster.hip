@@ -118,6 +118,10 @@ __global__ void __launch_bounds__(256) ranges_kernel(const int32_t* __restrict__
         ranges[2 * c + 1] = N;
         n_clusters[0] = c + 1;
         n_clusters[1] = head->overflow;     // the overflow flag of keys_kernel travels with the cluster count
+        for (int d = 0; d < 3; ++d) {       // ... and so do the voxel bounds of the cloud: its bounding box, to one voxel
+            n_clusters[2 + d] = head->qmin[d] == INT_MAX ? 0 : head->qmin[d];
+            n_clusters[5 + d] = head->qmax[d] == INT_MIN ? 0 : head->qmax[d];
+        }
     }
 }
 
@@ -415,7 +419,7 @@ int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in
     if (!n_clusters) return fail(GLHIP_EINVAL, "glhip_grid_cluster: NULL n_clusters");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (N == 0) {
-        (void)hipMemsetAsync(n_clusters, 0, 2 * sizeof(int32_t), st);
+        (void)hipMemsetAsync(n_clusters, 0, 8 * sizeof(int32_t), st);
         return GLHIP_OK;
     }
     if (!x || !perm || !ranges || !centroids || !weights_c || !workspace)

@@ -77,6 +77,7 @@ class ShardedSamplesLoss(torch.nn.Module):
         if getattr(loss, "diameter", None) is None and getattr(loss, "loss", None) == "sinkhorn":
             loss = copy.copy(loss)  # same schedule on every rank as the unsharded reference computation
             loss.diameter = global_diameter(x.detach(), y.detach(), self.group)
+            loss._diameter_bounds_the_data = True       # measured: the HIP soft-mins may size their exponent layout on it
         if x.shape[0] == 0:      # nothing on this rank: it still takes part in the collectives above and below
             local = x.new_zeros(0, dtype=torch.float32) + 0.0 * x.sum()
         else:

@@ -427,7 +427,8 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True, defer=False):
     cloud in cluster order (None without ``gather``); ``ranges`` (C,2) int32, ``centroids`` (C,D) fp32 of ``x / pre_div``,
     ``weights_c`` (C,) fp32.  One host read-back (the cluster count) sizes the outputs — with ``defer`` the launch is queued and
     ``(count tensor, finish)`` comes back instead: the caller reads the counts of several clusterings in one round trip
-    (:func:`read_back`) and calls ``finish(count values)`` for the tuple above."""
+    (:func:`read_back`) and calls ``finish(count values)`` for the tuple above.  The count tensor holds 8 integers, ``{C, overflow,
+    qmin[3], qmax[3]}``: the voxel bounds of the cloud travel in the same round trip (:func:`voxel_extent`)."""
     lib = load_library()
     N, D = x.shape
     dev = x.device
@@ -438,7 +439,7 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True, defer=False):
         ranges = torch.empty((N, 2), dtype=torch.int32, device=dev)
         cents = torch.empty((N, D), dtype=torch.float32, device=dev)
         w_c = torch.empty(N, dtype=torch.float32, device=dev)
-        count = torch.empty(2, dtype=torch.int32, device=dev)
+        count = torch.empty(8, dtype=torch.int32, device=dev)        # {C, overflow, qmin[3], qmax[3]}
         nbytes = int(lib.glhip_cluster_workspace_bytes(N, D))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
@@ -448,13 +449,23 @@ def grid_cluster_raw(x, weights, voxel, pre_div=1.0, gather=True, defer=False):
     _check(rc, lib)
 
     def finish(values):
-        C, overflow = values
+        C, overflow = values[:2]
         if overflow:
             raise ValueError("geomloss_amd: the voxel grid has more than 2^21 cells along an axis; use a larger cluster_scale.")
         return perm, x_sorted, w_sorted, ranges[:C], cents[:C], w_c[:C]
     if defer:
         return count, finish
     return finish(read_back(count)[0])      # the one host round trip
+
+
+def voxel_extent(count_values, voxel, pre_div=1.0):
+    """Upper bound of the diagonal of the joint bounding box of the clouds whose ``glhip_grid_cluster`` count values (8 integers
+    each, same ``voxel`` and ``pre_div``) are given: every cloud lies in [qmin, qmax + 1) voxels along each axis."""
+    live = [v for v in count_values if v[0] > 0]
+    if not live:
+        return 0.0
+    side = [(max(v[5 + d] for v in live) + 1 - min(v[2 + d] for v in live)) * float(voxel) * float(pre_div) for d in range(3)]
+    return float(sum(s * s for s in side) ** 0.5)
 
 
 # intervals: up to here the worst-case buffers (2 x 32 MB of address space the kernels touch the used part of) are cheaper than the

@@ -160,6 +160,8 @@ class SamplesLoss(Module):
             p=self.p, blur=self.blur, reach=self.reach, diameter=self.diameter, scaling=self.scaling,
             truncate=self.truncate, cost=self.cost, kernel=self.kernel, cluster_scale=self.cluster_scale,
             debias=self.debias, potentials=self.potentials, labels_x=l_x, labels_y=l_y, verbose=self.verbose,
+            # (set by ShardedSamplesLoss on its copy: `diameter` is the all-reduced bounding box, a true bound of this shard)
+            diameter_bounds_the_data=getattr(self, "_diameter_bounds_the_data", False),
         )
 
         if self.potentials:

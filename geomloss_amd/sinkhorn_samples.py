@@ -23,7 +23,7 @@ import torch
 from . import hip
 from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, clusterize_device_many, from_matrix,
                       grid_cluster, kept_pairs_device, native_clustering_applies, swap_axes)
-from .sinkhorn_divergence import log_weights, log_weights_many, scaling_parameters, sinkhorn_cost, sinkhorn_loop
+from .sinkhorn_divergence import log_weights, log_weights_many, max_diameter, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
 # ==============================================================================
@@ -133,14 +133,16 @@ class _HipSoftmin:
             hit = self._dist_plans[key] = (x, y, hip.compact_rows_plan(x, y))
         return hit[2]
 
-    def set_range(self, diameter, measured):
-        """Tells the soft-min how wide the clouds are, so that it can ask for the f16 x 2 exponent layout (GLHIP_FLAG_F16X2: about half
-        the matrix instructions and LDS bytes of the default bf16 x 3 one) where the exponents fit f16's range: terms of size
-        log2(e) diameter^2 / eps must stay below ~2.6e5.  With a diameter measured on the data that is eps >= 2e-5 diameter^2 (a
-        factor 3 of headroom); a diameter GIVEN by the caller only parametrises the schedule and may understate the clouds, so it
-        gets a factor 15 (eps >= 1e-4 diameter^2: blur / diameter >= 0.01).  p = 2 only; GEOMLOSS_HIP_F16X2=0 keeps bf16 x 3."""
-        if self.p == 2 and _F16X2 and diameter is not None and diameter > 0:
-            self.h2_min_eps = (2e-5 if measured else 1e-4) * float(diameter) ** 2
+    def set_range(self, extent):
+        """Tells the soft-min how wide the clouds ARE (the diagonal of their bounding box, or an upper bound of it; None: unknown),
+        so that it can ask for the f16 x 2 exponent layout (GLHIP_FLAG_F16X2: about half the matrix instructions and LDS bytes of
+        the default bf16 x 3 one) where the exponents fit f16's range: terms of size log2(e) extent^2 / eps must stay below ~2.6e5,
+        i.e. eps >= 2e-5 extent^2 with a factor 3 of headroom.  The extent is always MEASURED on the data: a ``diameter=`` given by
+        the caller only parametrises the schedule (``_legacy/sinkhorn_divergence.py:154-163``) and may understate the clouds, so
+        it is never used here (round 5 trusted it with a factor 15 and returned inf / nan on understated values).
+        p = 2 only; GEOMLOSS_HIP_F16X2=0 keeps bf16 x 3."""
+        if self.p == 2 and _F16X2 and extent is not None and extent > 0:
+            self.h2_min_eps = 2e-5 * float(extent) ** 2
 
     def _flags(self, eps):
         return hip.FLAG_F16X2 if eps >= self.h2_min_eps else 0
@@ -271,6 +273,26 @@ def set_iteration_fusion(enabled):
     _fuse_iterations = bool(enabled)
 
 
+# A given `diameter` says nothing reliable about the data (set_range): online losses of at least this many pairs per soft-min measure
+# the bounding box themselves — one small reduction and its read-back, < 1 % of such a loss — smaller ones stay on bf16 x 3, where
+# the host bounds the run time anyway and a synchronisation would cost more than the layout gains.
+_EXTENT_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_EXTENT_MIN_PAIRS", "2e8"))
+
+
+def _extent_for_range(x, y, diameter, diameter_given, bounds_the_data=False):
+    """The extent `_HipSoftmin.set_range` may rely on: the measured diameter; a given one only if the caller vouches that it bounds
+    the data (``ShardedSamplesLoss``: the all-reduced bounding box); otherwise a measurement for big problems, None for small ones."""
+    if not diameter_given or bounds_the_data:
+        return diameter
+    B = 1 if x.dim() == 2 else x.shape[0]
+    if not _F16X2 or _graph_mode or float(B) * x.shape[-2] * y.shape[-2] < _EXTENT_MIN_PAIRS:
+        return None
+    D = x.shape[-1]
+    if x.dtype in (torch.bfloat16, torch.float16):
+        x, y = x.float(), y.float()
+    return max_diameter(x.detach().reshape(-1, D), y.detach().reshape(-1, D))
+
+
 def sinkhorn_online(
     a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, cost=None, debias=True,
     potentials=False, **kwargs,
@@ -291,7 +313,7 @@ def sinkhorn_online(
     C_xy, C_yx = ((x, y.detach()), (y, x.detach()))
 
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
-    softmin.set_range(diameter, measured=not diameter_given)
+    softmin.set_range(_extent_for_range(x, y, diameter, diameter_given, kwargs.get("diameter_bounds_the_data", False)))
 
     a_log, b_log = log_weights_many([a, b])
     # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
@@ -521,14 +543,17 @@ def sinkhorn_multiscale(
 
     diameter_given = diameter is not None
     diameter, eps, eps_list, rho = scaling_parameters(x, y, p, blur, reach, diameter, scaling)
-    softmin.set_range(diameter, measured=not diameter_given)
 
     # voxel size: about 2000 cells over the bounding box
     if cluster_scale is None:
         cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
     if native_clustering_applies(x, labels_x) and native_clustering_applies(y, labels_y):      # both clusterings, one host round trip
-        (a_c, a, x_c, x, ranges_x, perm_x), (b_c, b, y_c, y, ranges_y, perm_y) = clusterize_device_many([(a, x), (b, y)], cluster_scale, long_perm=False)
+        box = []         # ... which also brings back the voxel bounds of the clouds: their true extent when `diameter` was given
+        (a_c, a, x_c, x, ranges_x, perm_x), (b_c, b, y_c, y, ranges_y, perm_y) = clusterize_device_many(
+            [(a, x), (b, y)], cluster_scale, long_perm=False, extent=box)
+        softmin.set_range(box[0] if diameter_given else diameter)
     else:
+        softmin.set_range(None if diameter_given else diameter)
         [a_c, a], [x_c, x], [ranges_x], perm_x = clusterize(a, x, scale=cluster_scale, labels=labels_x)
         [b_c, b], [y_c, y], [ranges_y], perm_y = clusterize(b, y, scale=cluster_scale, labels=labels_y)
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 113 /* 0.1.13 */
+#define GLHIP_VERSION 114 /* 0.1.14 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -353,8 +353,12 @@ int glhip_max_lines_fwd(const float* g, float* out, long R, int N, float step, i
  *   x (N,D) fp32|bf16, D <= 3;  weights (N) fp32 or NULL (all ones)
  *   perm (N) int32 out: sorted row p is input row perm[p];   x_sorted (N,D) / w_sorted (N) out, may be NULL
  *   ranges (N,2) int32, centroids (N,D) fp32 (weighted means of x / pre_div), weights_c (N) fp32: the first C rows are
- *   written, C <= N = the number of non-empty voxels;  n_clusters (2) int32 out: {C, overflow} — overflow != 0 means a
- *   voxel coordinate exceeded 2^21 bins along an axis (result invalid; use a larger voxel).
+ *   written, C <= N = the number of non-empty voxels;  n_clusters (8) int32 out: {C, overflow, qmin[3], qmax[3]} — overflow != 0
+ *   means a voxel coordinate exceeded 2^21 bins along an axis (result invalid; use a larger voxel); qmin / qmax are the smallest
+ *   and largest voxel index of the cloud along each axis (0 beyond D; since version 114): the cloud lies in the box
+ *   [qmin voxel pre_div, (qmax + 1) voxel pre_div) — its bounding box to one voxel, which is how a caller that was GIVEN a
+ *   diameter (it only parametrises the schedule, _legacy/sinkhorn_divergence.py:154-163) learns the true extent of the data
+ *   before vouching for GLHIP_FLAG_F16X2, in the round trip that reads C anyway.
  * Sums are accumulated in float64 in a fixed order: the same inputs give the same centroids bit for bit.  Nothing comes
  * back to the host: read n_clusters when the sizes are needed.  workspace: glhip_cluster_workspace_bytes(N, D).
  *

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden, relerr
+from conftest import golden_cases, load_golden, multiscale_cases, relerr
 from geomloss_amd import SamplesLoss, hip
 from oracle import oracle_c, oracle_np
 
@@ -130,6 +130,68 @@ def test_multiscale_matches_two_scale_oracle(cuda, kind, scaling, fine_level):
     Fo, Go = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), p=2, blur=0.05,
                                            scaling=scaling, truncate=5, potentials=True)
     assert relerr(Fm.cpu().numpy(), Fo) < 1e-4 and relerr(Gm.cpu().numpy(), Go) < 1e-4
+
+
+@pytest.mark.parametrize("name", multiscale_cases())
+def test_multiscale_matches_reference_driver_runs(cuda, name, fine_level):
+    """The HIP two-scale path against float64 runs of the REFERENCE's own `sinkhorn_multiscale` (`_legacy/sinkhorn_samples.py:
+    547-681`; tests/golden/make_golden_multiscale.py hands it dense stand-ins for its pykeops primitives): loss, gradients,
+    potentials in the caller's order, at the 1e-4 bar of BASELINE.json — p = 1 / 2, D = 1..3, weights, `reach`, `debias=False`,
+    `truncate`, a user `cluster_scale`, a given `diameter`, the jump on the last iteration, same-law clouds, negative coordinates."""
+    rec = load_golden(name)
+    kw = dict(rec["kwargs"])
+    kw.pop("loss")
+    a, x, b, y = _inputs(rec, cuda)
+    L = SamplesLoss("sinkhorn", backend="multiscale", **kw)(a, x, b, y)
+    assert abs(L.item() - float(rec["loss_f64"])) <= 1e-4 * abs(float(rec["loss_f64"]))
+    gx, ga = torch.autograd.grad(L, [x, a])
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < 1e-4
+    assert relerr(ga.cpu().numpy(), rec["ga_f64"]) < 1e-4
+    F, G = SamplesLoss("sinkhorn", backend="multiscale", potentials=True, **kw)(a.detach(), x.detach(), b, y)
+    assert F.shape == rec["F_f64"].shape
+    assert relerr(F.cpu().numpy(), rec["F_f64"]) < 1e-4 and relerr(G.cpu().numpy(), rec["G_f64"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", multiscale_cases(kernels=True))
+def test_kernel_multiscale_matches_reference_driver_runs(cuda, monkeypatch, name):
+    """The HIP block-sparse kernel norms against float64 runs of the REFERENCE's own `kernel_multiscale`
+    (`_legacy/kernel_samples.py:177-271`).  Potentials: like the reference, in cluster-sorted order — compared per point
+    through the permutation each side applied."""
+    from geomloss_amd import kernel_samples as ks
+    rec = load_golden(name)
+    kw = dict(rec["kwargs"])
+    loss = kw.pop("loss")
+    a, x, b, y = _inputs(rec, cuda)
+    perms, inner_device, inner_sort = [], ks.clusterize_device, ks.sort_clusters
+
+    def spy_device(*args, **kwargs):             # records the permutation the product sorts each cloud with
+        out = inner_device(*args, **kwargs)
+        perms.append(out[-1])
+        return out
+
+    def spy_sort(t, lab):
+        perms.append(torch.sort(lab.view(-1), stable=True)[1])
+        return inner_sort(t, lab)
+    monkeypatch.setattr(ks, "clusterize_device", spy_device)
+    monkeypatch.setattr(ks, "sort_clusters", spy_sort)
+    L = SamplesLoss(loss, backend="multiscale", **kw)(a, x, b, y)
+    ref = float(np.asarray(rec["loss_f64"]).reshape(-1)[0])
+    assert abs(float(L.detach().reshape(-1)[0]) - ref) <= 1e-4 * abs(ref)
+    gx, ga = torch.autograd.grad(L.sum(), [x, a])
+    assert relerr(gx.cpu().numpy(), rec["gx_f64"]) < 1e-4
+    assert relerr(ga.cpu().numpy().reshape(-1), rec["ga_f64"].reshape(-1)) < 1e-4
+    F, G = SamplesLoss(loss, backend="multiscale", potentials=True, **kw)(a.detach(), x.detach(), b, y)
+    F, G = F.cpu().numpy().reshape(-1), G.cpu().numpy().reshape(-1)
+    Fr, Gr = rec["F_f64"].reshape(-1), rec["G_f64"].reshape(-1)
+    if "perm_x" in rec:
+        # compared per point: un-sort the reference with the permutation its run recorded, ours with the one the product applied
+        px, py = perms[-2], perms[-1]
+        Fu, Gu = np.empty_like(F), np.empty_like(G)
+        Fu[px.cpu().numpy()], Gu[py.cpu().numpy()] = F, G
+        Fru, Gru = np.empty_like(Fr), np.empty_like(Gr)
+        Fru[rec["perm_x"]], Gru[rec["perm_y"]] = Fr, Gr
+        F, G, Fr, Gr = Fu, Gu, Fru, Gru
+    assert relerr(F, Fr) < 1e-4 and relerr(G, Gr) < 1e-4
 
 
 def test_multiscale_verbose_runs_the_same_kernels(cuda, capsys):
@@ -544,3 +606,41 @@ def test_two_scale_loss_host_round_trips(cuda, monkeypatch):
     assert trips == [2, 3], trips          # (clusters of x and y), (kept pairs of xy, xx, yy): two round trips with a given diameter
     ref = SamplesLoss("sinkhorn", p=2, blur=0.05, diameter=1.8, backend="online")(x, y)
     assert abs(L.item() - ref.item()) < 0.2 * abs(ref.item())      # (sanity: the two-scale answer is the same loss up to its truncation)
+
+
+@pytest.mark.parametrize("backend,measure", [("online", True), ("online", False), ("multiscale", True)])
+def test_understated_diameter_is_legal(cuda, monkeypatch, backend, measure):
+    """`diameter=` only parametrises the schedule (`_legacy/sinkhorn_divergence.py:154-163`): a value TEN times too small is legal in
+    the reference.  Round 5 sized the f16 x 2 exponent layout on it and returned inf / nan here (true extent^2 / eps = 3.3e5);
+    now the layout is sized on the data — the voxel bounds that come back with the cluster counts (multiscale), a measured bounding
+    box (big online problems; forced here through the threshold) — or not asked for (small online problems)."""
+    import geomloss_amd.sinkhorn_samples as ss
+    monkeypatch.setattr(ss, "_EXTENT_MIN_PAIRS", 0.0 if measure else 1e30)
+    extents = []
+    inner = ss._HipSoftmin.set_range
+    monkeypatch.setattr(ss._HipSoftmin, "set_range", lambda self, extent: (extents.append(extent), inner(self, extent))[1])
+    N, M = 1500, 1400
+    rng = np.random.default_rng(21)
+    x, y = rng.random((N, 3)).astype(np.float32) * 10, (rng.random((M, 3)).astype(np.float32) * 0.8 + 0.1) * 10
+    true_diam = float(np.linalg.norm(np.maximum(x.max(0), y.max(0)) - np.minimum(x.min(0), y.min(0))))
+    kw = dict(p=2, blur=0.03, scaling=0.6, diameter=true_diam / 10)
+    xt, yt = torch.from_numpy(x).to(cuda).requires_grad_(True), torch.from_numpy(y).to(cuda)
+    L = SamplesLoss("sinkhorn", backend=backend, **kw)(xt, yt)
+    (gx,) = torch.autograd.grad(L, [xt])
+    assert torch.isfinite(L) and torch.isfinite(gx).all()
+    a, b = np.full(N, 1 / N), np.full(M, 1 / M)
+    if backend == "online":
+        ref, ref_gx, _ = oracle_np.sinkhorn_loss_and_grad(x.astype(np.float64), y.astype(np.float64), a, b, **kw)
+    else:
+        ref, ref_gx = oracle_np.sinkhorn_multiscale(a, x.astype(np.float64), b, y.astype(np.float64), grad=True, **kw)
+    assert abs(L.item() - ref) <= 1e-4 * abs(ref)
+    assert relerr(gx.cpu().numpy(), ref_gx) < 1e-4
+    # what the layout was sized on: the data (to one voxel for the two-scale backend), never the given value
+    assert len(extents) == 1 and (extents[0] is not None) == measure
+    if measure:
+        assert true_diam * 0.999 <= extents[0] <= true_diam + 4 * kw["diameter"] / 12
+    # an OVERstated diameter changes nothing about the range either
+    L2 = SamplesLoss("sinkhorn", backend=backend, **dict(kw, diameter=true_diam * 3, blur=0.5))(xt.detach(), yt)
+    assert torch.isfinite(L2) and (extents[1] is not None) == measure
+    if measure:
+        assert true_diam * 0.999 <= extents[1] <= true_diam * 1.5
