@@ -122,13 +122,14 @@ void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, c
     else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
 
-template <int D, typename T, int KIND, int NW, int L = XL_BF16X3>
+template <int D, typename T, int KIND, int NW, int L = XL_BF16X3, int RT = 1>
 void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                             const Scratch& sc, hipStream_t st) {
     static_assert(L == XL_BF16X3 || KIND == FWD_X32, "the f16 x 2 layout exists on the 32x32x16 kernel only");
+    static_assert(RT == 1 || (KIND == FWD_X32 && NW == 4), "two row tiles per wavefront: block-sparse pre-packed launches of the 32x32x16 kernel");
     constexpr int NR = X32Layout<L>::NR;
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
-    constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
+    constexpr int kRowsPerBlock = NW * 32 * RT;        // 16 * kFwdRT = 32 rows per wavefront in all three kernels (x RT row tiles, x32 only)
     static_assert(kFwdRT == 2, "row tiling of the forward kernels");
     unsigned chunk_grid = 0;   // block-sparse: one workgroup per row chunk of kRowsPerBlock rows (build_row_chunks_kernel)
     const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid) : rg;
@@ -196,9 +197,11 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (n_ranges > 0) {
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
-        } else {
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, RT, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
+        } else if constexpr (RT == 1) {
             launch_fwd_kernel<D, T, KIND, NW, true, L>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
+        } else {
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, RT, NW, false, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, PackedCols{nullptr, 0});
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -226,7 +229,13 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
     if constexpr (KIND == FWD_X32) {
         if (sc.h2) {      // GLHIP_FLAG_F16X2: the same kernel on the f16 x 2 layout (one MFMA per block); same workgroup shapes
+            static const int forced_rt = getenv("GLHIP_FWD_RT") ? atoi(getenv("GLHIP_FWD_RT")) : 0;   // tuning knob (1 or 2)
+            const bool big_blocks = n_ranges > 0 && (double)B * N * M >= 5e8 && N / n_ranges >= 192;
             if (n_ranges > 0 && sc.small_rows && !forced_nw) launch_softmin_mfma_nw<D, T, FWD_X32, 2, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
+            else if (big_blocks && forced_rt == 2 && !forced_nw)
+                // block-sparse, row blocks of hundreds of points: 4 wavefronts x 2 row tiles — the same 256 rows per workgroup, each column
+                // record read from LDS once for two 32 x 32 blocks
+                launch_softmin_mfma_nw<D, T, FWD_X32, 4, XL_F16X2, 2>(prm, rg, n_ranges, B, N, M, sc, st);
             else if (forced_nw ? forced_nw == 8 : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
                 launch_softmin_mfma_nw<D, T, FWD_X32, 8, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
             else launch_softmin_mfma_nw<D, T, FWD_X32, 4, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
@@ -263,6 +272,15 @@ void launch_wsum_kernel(bool x32, bool pre, dim3 grid, hipStream_t st, const Wsu
     if constexpr (wsum_uses_x32<MODE>()) {
         if (x32 && pre) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
         if (x32) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, false>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
+    }
+    if constexpr (MODE == WS_SOFTMIN_BWD) {
+        // long column runs: re-based moments (glhip_wsum_mfma.h) — the rounding of M / 16 additions at the size of the row's offset
+        // from the workgroup centre is what limited the same-law gradients at N = 1e6
+        static const long rebase_min = getenv("GLHIP_REBASE_MIN") ? atol(getenv("GLHIP_REBASE_MIN")) : 8192;
+        if ((long)M >= rebase_min) {
+            hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+            return;
+        }
     }
     hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }

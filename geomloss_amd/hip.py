@@ -674,6 +674,88 @@ def _plan_for(plan, xb, yb, ranges, flags):
 #  autograd functions
 # ----------------------------------------------------------------------------------------------
 
+def _plan_moments(xb, yb, hb, out, eps, ranges, flags):
+    """S_i = sum_j P_ij u_j u_j^T (B,N,D,D) and the centre c (B,1,D), u_j = y_j - c, for the plan P_ij = exp(h_j - |x_i - y_j|^2 / (2 eps)
+    + out_i / eps) of a p = 2 soft-min — from the EXISTING gradient reduction (``glhip_softmin_bwd_x``), on augmented clouds:
+    x' = (x, 0), y' = (y, t q_j), h' = h + t^2 |q_j|^2 / (2 eps) leave every P_ij unchanged (the extra squared distance cancels
+    against the shift of h), and the extra components of sum_j P_ij (x'_i - y'_j) are -t sum_j P_ij q_j: any average of column
+    features q_j under the plan, here q = the D (D + 1) / 2 products u_a u_b.  t = sqrt(eps) / max |q| keeps the shift of h of
+    order one; D + features <= 16 per call keeps the matrix-core kernels."""
+    B, N, D = xb.shape
+    xf, yf = xb.float(), yb.float()
+    c = yf.mean(1, keepdim=True)
+    u = yf - c
+    ia, ib = torch.triu_indices(D, D, device=xb.device)
+    q = u[..., ia] * u[..., ib]                                    # (B, M, K)
+    K = q.shape[-1]
+    t = (eps ** 0.5) / q.abs().amax().clamp_min(1e-30)             # device scalar: no host round trip
+    chunk = (XD_MAX_DIM - D) if D <= XD_MAX_DIM - 4 else 8
+    ones = torch.ones((B, N), dtype=torch.float32, device=xb.device)
+    mom = torch.empty((B, N, K), dtype=torch.float32, device=xb.device)
+    flags = int(flags) & ~(FLAG_F16X2 | FLAG_MFMA_DIST)
+    for k0 in range(0, K, chunk):
+        qa = q[..., k0:k0 + chunk] * t
+        ya = torch.cat([yf, qa], -1).contiguous()
+        xa = torch.cat([xf, torch.zeros((B, N, qa.shape[-1]), dtype=torch.float32, device=xb.device)], -1).contiguous()
+        ha = (hb.float() + (qa * qa).sum(-1) / (2.0 * eps)).contiguous()
+        r = softmin_bwd_x_raw(xa, ya, ha, out, ones, eps, 2, ranges, flags)
+        mom[..., k0:k0 + chunk] = r[..., D:] / (-t)
+    S = torch.empty((B, N, D, D), dtype=torch.float32, device=xb.device)
+    S[..., ia, ib] = mom
+    S[..., ib, ia] = mom
+    return S, c
+
+
+class _SoftminBwdX(torch.autograd.Function):
+    """G_i = g_i d f_i / d x_i, the backward pass of the soft-min as a differentiable operation of (x, g): what
+    ``torch.autograd.grad(..., create_graph=True)`` records (KeOps' `Grad` of `_legacy/sinkhorn_samples.py:322-334`
+    is differentiable again, `_legacy/sinkhorn_divergence.py:612-623` leaves autograd on for that).  y and h carry no gradient:
+    the Sinkhorn loop detaches them.
+
+    p = 2: d f_i / d x_i = x_i - ybar_i with ybar_i = sum_j P_ij y_j, so for a cotangent V (B,N,D)
+        d<V, G> / d g_i = V_i . (x_i - ybar_i)
+        d<V, G> / d x_i = g_i [ V_i - Cov_i V_i / eps ],   Cov_i = sum_j P_ij y_j y_j^T - ybar_i ybar_i^T
+    (d P_ij / d x_i = P_ij (y_j - ybar_i) / eps).  The second moments come from :func:`_plan_moments`: one or a few more calls of
+    the gradient kernel, O(N + M) memory at any size.  p = 1: the Hessian of |x - y| makes the column features depend on the row;
+    d / d g is served, d / d x raises (``backend="tensorized"`` is differentiable to any order)."""
+
+    @staticmethod
+    def forward(ctx, x, g, yb, hb, out, eps, p, ranges, flags):
+        xb = _points(x.detach(), "x", True)
+        ones = torch.ones_like(out)
+        unit = softmin_bwd_x_raw(xb, yb, hb, out, ones, eps, p, ranges, flags)       # d f_i / d x_i
+        ctx.save_for_backward(xb, g.detach(), yb, hb, out, unit)
+        ctx.cfg = (eps, p, ranges, flags, x.dtype, g.dtype)
+        return (g.detach().to(unit.dtype).unsqueeze(-1) * unit).to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, V):
+        xb, g, yb, hb, out, unit = ctx.saved_tensors
+        eps, p, ranges, flags, xdtype, gdtype = ctx.cfg
+        V = V.reshape(unit.shape).to(unit.dtype)
+        grad_g = (V * unit).sum(-1).to(gdtype) if ctx.needs_input_grad[1] else None
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            if p != 2 or is_f64(xb):
+                raise NotImplementedError(
+                    "geomloss_amd: second-order derivatives with respect to the points are implemented for the p = 2 HIP soft-min "
+                    "on float32 / bfloat16 clouds; use backend='tensorized' (differentiable to any order) for p = 1 or float64.")
+            S, c = _plan_moments(xb, yb, hb, out, eps, ranges, flags)
+            ubar = (xb.float() - c) - unit                                           # sum_j P_ij (y_j - c)
+            cov_v = torch.einsum("bnde,bne->bnd", S, V) - ubar * (ubar * V).sum(-1, keepdim=True)
+            grad_x = (g.to(unit.dtype).unsqueeze(-1) * (V - cov_v / eps)).to(xdtype)
+        return grad_x, grad_g, None, None, None, None, None, None, None
+
+
+def _bwd_x(x, g, yb, hb, out, eps, p, ranges, flags):
+    """g_i d f_i / d x_i (B,N,D): one reduction — or, while autograd records the backward pass (``create_graph=True``), the
+    differentiable node above.  ``x``: the (B,N,D) view of the tensor the caller differentiates."""
+    if torch.is_grad_enabled() and (x.requires_grad or g.requires_grad):
+        return _SoftminBwdX.apply(x, g, yb, hb, out, eps, p, ranges, flags)
+    return softmin_bwd_x_raw(_points(x.detach(), "x", True), yb, hb, out, g.detach().to(out.dtype).contiguous(), eps, p, ranges, flags)
+
+
 class _Softmin(torch.autograd.Function):
     """f_i = -eps log sum_j exp(h_j - C(x_i,y_j)/eps); differentiable in x only, like the reference's call sites."""
 
@@ -689,23 +771,21 @@ class _Softmin(torch.autograd.Function):
             if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
                 flags |= FLAG_MFMA_DIST            # multiscale: the row blocks are voxel clusters already
             out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
-        ctx.save_for_backward(xb, yb, hb, out)
-        ctx.cfg = (eps, p, ranges, flags, x.shape, x.dtype)
+        ctx.save_for_backward(x, yb, hb, out)         # (x itself: under create_graph the backward pass is differentiated through it)
+        ctx.cfg = (eps, p, ranges, flags, xb.shape)
         return out if batched else out.view(-1)
 
     @staticmethod
-    @once_differentiable        # second-order derivatives through the HIP soft-min: autograd raises if they are asked for (backend="tensorized" is differentiable to any order)
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out):      # differentiable once more under create_graph=True (_SoftminBwdX)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise NotImplementedError(
                 "geomloss_amd: the HIP soft-min is differentiable with respect to its first point cloud only "
                 "(the Sinkhorn loop detaches the second cloud and the dual vector)."
             )
-        xb, yb, hb, out = ctx.saved_tensors
-        eps, p, ranges, flags, xshape, xdtype = ctx.cfg
-        g = grad_out.reshape(out.shape).to(out.dtype).contiguous()
-        gx = softmin_bwd_x_raw(xb, yb, hb, out, g, eps, p, ranges, flags)
-        return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None, None
+        x, yb, hb, out = ctx.saved_tensors
+        eps, p, ranges, flags, bshape = ctx.cfg
+        gx = _bwd_x(x.reshape(bshape), grad_out.reshape(out.shape), yb, hb, out, eps, p, ranges, flags)
+        return gx.reshape(x.shape).to(x.dtype), None, None, None, None, None, None, None
 
 
 class _SoftminValueGrad(torch.autograd.Function):
@@ -718,15 +798,20 @@ class _SoftminValueGrad(torch.autograd.Function):
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
         out, unit = softmin_fwd_grad_raw(xb, yb, hb, _f32(guess).reshape(hb.shape[0], -1), margin, eps, ranges, flags)
-        ctx.unit, ctx.cfg = unit, (x.shape, x.dtype)
+        ctx.unit, ctx.cfg = unit, (x.shape, x.dtype, eps, ranges, flags)
+        ctx.save_for_backward(x, yb, hb, out)         # for a backward pass that is differentiated again (create_graph=True)
         return out if batched else out.view(-1)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad_out):
-        xshape, xdtype = ctx.cfg
-        g = grad_out.reshape(ctx.unit.shape[0], -1).float()
-        return (g.unsqueeze(-1) * ctx.unit).reshape(xshape).to(xdtype), None, None, None, None, None, None, None
+        xshape, xdtype, eps, ranges, flags = ctx.cfg
+        g = grad_out.reshape(ctx.unit.shape[0], -1)
+        x, yb, hb, out = ctx.saved_tensors
+        if torch.is_grad_enabled() and (x.requires_grad or g.requires_grad):
+            gx = _SoftminBwdX.apply(x.reshape(ctx.unit.shape), g, yb, hb, out, eps, 2, ranges, flags)
+        else:
+            gx = g.float().unsqueeze(-1) * ctx.unit
+        return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None, None
 
 
 _VALUE_GRAD_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_VALUE_GRAD_MIN_PAIRS", "5e8"))
@@ -882,31 +967,32 @@ class _Last4(torch.autograd.Function):
     def forward(ctx, x, y, plan, eps, damping, *pots):
         outs = plan.run(eps, damping, tuple(p.detach() for p in pots), last=True)
         ctx.plan, ctx.cfg, ctx.extra_flags = plan, (eps, damping, x.shape, x.dtype, y.shape, y.dtype), plan.extra_flags
-        ctx.save_for_backward(*pots, *outs)
+        ctx.save_for_backward(x, y, *(p.detach() for p in pots), *outs)
         return outs
 
     @staticmethod
-    @once_differentiable
-    def backward(ctx, *grads):
+    def backward(ctx, *grads):        # differentiable once more under create_graph=True (_SoftminBwdX)
         plan = ctx.plan
         eps, damping, xshape, xdtype, yshape, ydtype = ctx.cfg
         B = plan.dims[0]
-        saved = ctx.saved_tensors
+        x_in, y_in = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors[2:]
         k = len(saved) // 2
         pots, outs = saved[:k], saved[k:]
         # (rows, columns, log-weights of the columns, potential carried by the columns) of each reduction
-        specs = [(plan.x, plan.y, plan.b_log, pots[1]), (plan.y, plan.x, plan.a_log, pots[0])]
+        specs = [(x_in, plan.y, plan.b_log, pots[1]), (y_in, plan.x, plan.a_log, pots[0])]
         if k == 4:
-            specs += [(plan.x, plan.x, plan.a_log, pots[2]), (plan.y, plan.y, plan.b_log, pots[3])]
+            specs += [(x_in, plan.x, plan.a_log, pots[2]), (y_in, plan.y, plan.b_log, pots[3])]
         gx = gy = None
+        with torch.no_grad():
+            hs = [logw + pot.reshape(B, -1) * (1.0 / eps) for _, _, logw, pot in specs]
+            vals = [(outs[i].reshape(B, -1) * (1.0 / damping)).contiguous() for i in range(k)]      # the soft-min values themselves
         for i, (rows, cols, logw, pot) in enumerate(specs):
             g = grads[i]
             if g is None or not ctx.needs_input_grad[i % 2]:
                 continue
-            h = logw + pot.reshape(B, -1) * (1.0 / eps)
-            out = outs[i].reshape(B, -1) * (1.0 / damping)            # the soft-min value itself
-            gr = softmin_bwd_x_raw(rows, cols, h, out.contiguous(), (g.reshape(B, -1).float() * damping).contiguous(), eps, plan.p, None,
-                                   plan.flags | ctx.extra_flags)
+            gr = _bwd_x(rows.reshape(B, -1, rows.shape[-1]), g.reshape(B, -1) * damping, cols, hs[i], vals[i], eps, plan.p, None,
+                        plan.flags | ctx.extra_flags).float()
             if i % 2 == 0:
                 gx = gr if gx is None else gx + gr
             else:

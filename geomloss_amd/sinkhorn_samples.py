@@ -140,7 +140,12 @@ class _HipSoftmin:
         i.e. eps >= 2e-5 extent^2 with a factor 3 of headroom.  The extent is always MEASURED on the data: a ``diameter=`` given by
         the caller only parametrises the schedule (``_legacy/sinkhorn_divergence.py:154-163``) and may understate the clouds, so
         it is never used here (round 5 trusted it with a factor 15 and returned inf / nan on understated values).
-        p = 2 only; GEOMLOSS_HIP_F16X2=0 keeps bf16 x 3."""
+        p = 2 only; GEOMLOSS_HIP_F16X2=0 keeps bf16 x 3.
+
+        (Tried in round 6 and dropped: explicit differences, GLHIP_FLAG_DIRECT, for the temperatures below extent^2 / 4e4.  At
+        extent^2 / eps = 3.3e5 — blur / extent = 0.0017, tests/test_samples_loss_gpu.py::test_understated_diameter_is_legal — the
+        gradient went from 6.2e-4 to 3.8e-4 of its max-norm only: in that near-assignment regime the float32 dual potentials of
+        the earlier temperatures pass through unattenuated, whatever the last exponents are made of.  The loss is within 1e-4.)"""
         if self.p == 2 and _F16X2 and extent is not None and extent > 0:
             self.h2_min_eps = 2e-5 * float(extent) ** 2
 

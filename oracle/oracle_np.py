@@ -350,9 +350,14 @@ def kernel_loss_grad_x(name, x, y, a=None, b=None, blur=0.05, dtype=np.float64):
 # --------------------------------------------------------------------------------------------------
 
 
-def grid_cluster(x, size):
+def grid_cluster(x, size, label_dtype=None):
     """Voxel labels, compacted to 0..C-1 in lexicographic voxel order (pykeops.torch.cluster.grid_cluster
-    as used at sinkhorn_samples.py:477)."""
+    as used at sinkhorn_samples.py:477).  ``label_dtype``: the precision the bins `(x / size).floor()` are evaluated in — the
+    reference does it in the dtype of ``x``, and a float32 cloud of 1e6 points has a handful of coordinates whose quotient falls
+    on the other side of an integer in float64; a point in another voxel is another coarse problem (centroids move by 1e-4 of
+    a cluster), which showed as a 1e-6 step in dL/dx around that voxel (tools/diag_cfg3_grad.py, round 6)."""
+    if label_dtype is not None:
+        x, size = np.asarray(x).astype(label_dtype), np.dtype(label_dtype).type(size)
     q = np.floor(x / size).astype(np.int64)
     q -= q.min(0)
     ext = q.max(0) + 1
@@ -363,9 +368,9 @@ def grid_cluster(x, size):
     return lab
 
 
-def clusterize(a, x, scale):
+def clusterize(a, x, scale, label_dtype=None):
     """sinkhorn_samples.py:453-490: sorted cloud, per-cluster ranges, weighted centroids, summed weights."""
-    lab = grid_cluster(x, scale)
+    lab = grid_cluster(x, scale, label_dtype)
     counts = np.bincount(lab)
     a_c = np.bincount(lab, weights=a)
     x_c = np.stack([np.bincount(lab, weights=a * x[:, d]) for d in range(x.shape[1])], 1) / a_c[:, None]

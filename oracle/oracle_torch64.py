@@ -370,19 +370,31 @@ def _softmin_grad_obj(eps, Cobj, h, g, p, device):
 
 
 def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, scaling=0.5, truncate=5, cluster_scale=None,
-                        debias=True, potentials=False, grad=False, full=False, device=None, return_info=False):
+                        debias=True, potentials=False, grad=False, full=False, device=None, return_info=False,
+                        borderline_keeps=None, borderline_tol=1e-6):
     """``SamplesLoss("sinkhorn", backend="multiscale")`` for one pair of clouds at any size: the coarse level on dense NumPy
     matrices exactly as ``oracle_np.sinkhorn_multiscale`` (C ~ 2e3 clusters), the fine level on the device, a run of row
     clusters at a time (``_fine_reduce``).  ``full``: loss, dL/dx and the potentials (caller's point order) from ONE run of the
-    loop, as a dict."""
+    loop, as a dict.
+
+    ``borderline_keeps``: the cluster-level keep masks another implementation of the same algorithm decided, in the order the
+    loop truncates (xy, xx, yy).  The keep rule `f_i + g_j > C_ij - truncate eps` (sinkhorn_samples.py:512-514) is a threshold on
+    quantities two runs in different precisions agree on to ~1e-7 only, so among the ~5e6 cluster pairs of a 1e6-point problem
+    a handful sit within rounding of the threshold and are decided differently by a float32 and a float64 run of the SAME code
+    (the reference's own included) — each such pair moves the potentials of one cluster by ~eps e^-5 / (kept clusters) ~ 1e-7,
+    which is what dominated dL/dx of same-law clouds at N = 1e6 (profiles/r06_full_size_parity.txt).  With the masks given, the
+    oracle takes the OTHER side's decision for the pairs where the two differ — after asserting that every one of them is
+    borderline, |f_i + g_j - C_ij + truncate eps| <= ``borderline_tol`` — and counts them in ``info["borderline"]``."""
     device = default_device() if device is None else device
+    # voxel bins in the precision of the caller's clouds, as the reference evaluates them (oracle_np.grid_cluster)
+    label_dtype = np.float32 if isinstance(x, torch.Tensor) and x.dtype == torch.float32 else None
     a, x, b, y = (_host64(t) for t in (a, x, b, y))
     N, D = x.shape
     diameter, eps, eps_list, rho = oracle_np.scaling_parameters(x, y, p, blur, reach, diameter, scaling)
     if cluster_scale is None:
         cluster_scale = diameter / (np.sqrt(D) * 2000 ** (1 / D))
-    a_c, a, x_c, x, ranges_x, perm_x = oracle_np.clusterize(a, x, cluster_scale)
-    b_c, b, y_c, y, ranges_y, perm_y = oracle_np.clusterize(b, y, cluster_scale)
+    a_c, a, x_c, x, ranges_x, perm_x = oracle_np.clusterize(a, x, cluster_scale, label_dtype)
+    b_c, b, y_c, y, ranges_y, perm_y = oracle_np.clusterize(b, y, cluster_scale, label_dtype)
     jumps, eps_cost = [len(eps_list) - 1], eps
     for i, e in enumerate(eps_list[2:]):
         eps_cost = e                                   # the reference's shadowed `eps` (sinkhorn_samples.py:593-597)
@@ -393,7 +405,7 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
     # of at most one diameter (float64: ~1e-16 diam^2 / eps on an exponent)
     centre = 0.5 * (x.mean(0, keepdims=True) + y.mean(0, keepdims=True))
     xt, yt = _t(x - centre, device), _t(y - centre, device)
-    info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), kept_fraction=[], eps_list=eps_list)
+    info = dict(jumps=jumps, n_clusters=(len(x_c), len(y_c)), kept_fraction=[], eps_list=eps_list, borderline=[])
 
     def coarse(u, v, ru, rv):
         return dict(C=oracle_np.cost_matrix(u, v, p), x=u, y=v, ranges_x=ru, ranges_y=rv)
@@ -404,7 +416,17 @@ def sinkhorn_multiscale(a, x, b, y, p=2, blur=0.05, reach=None, diameter=None, s
     def kernel_truncation(C_xy, C_yx, C_xy_f, C_yx_f, f, g, eps_, truncate=None, cost=None):
         if truncate is None:
             return C_xy_f, C_yx_f
-        keep = f[:, None] + g[None, :] > C_xy["C"] - truncate * eps_            # sinkhorn_samples.py:512-514
+        slack = f[:, None] + g[None, :] - (C_xy["C"] - truncate * eps_)
+        keep = slack > 0                                                         # sinkhorn_samples.py:512-514
+        if borderline_keeps is not None:
+            other = borderline_keeps[len(info["kept_fraction"])]
+            other = keep if other is None else np.asarray(other, bool)      # None: the other side reduced this term densely
+            assert other.shape == keep.shape, (other.shape, keep.shape)
+            differ = other != keep
+            worst = float(np.abs(slack[differ]).max()) if differ.any() else 0.0
+            assert worst <= borderline_tol, f"{int(differ.sum())} keep decisions differ, one by a slack of {worst:.3e}: not a rounding matter"
+            info["borderline"].append((int(differ.sum()), worst))
+            keep = other
         ni, nj = np.diff(C_xy["ranges_x"], axis=1)[:, 0], np.diff(C_xy["ranges_y"], axis=1)[:, 0]
         info["kept_fraction"].append(float((ni[:, None] * nj[None, :] * keep).sum() / (ni.sum() * nj.sum())))
         return (_FineCost(C_xy_f.x, C_xy_f.y, C_xy["ranges_x"], C_xy["ranges_y"], keep),

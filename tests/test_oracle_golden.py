@@ -320,3 +320,23 @@ def test_kernel_two_scale_oracle_matches_reference_driver(name):
     if loss != "energy":
         _, gx = oracle_np.kernel_multiscale(loss, a, x, b, y, grad=True, **kw)
         assert relerr(gx, rec["gx_f64"]) < 1e-8
+
+
+def test_voxel_bins_follow_the_precision_of_the_cloud():
+    """`grid_cluster` evaluates `(x / size).floor()` in the dtype of x (pykeops.torch.cluster.grid_cluster on a float32 cloud works in
+    float32).  Among 1e6 float32 points a handful have a quotient on the other side of an integer in float64 — another voxel, another
+    coarse problem: ``label_dtype`` makes the oracle bin as a float32 run does (tests/test_full_size_gpu.py relies on it)."""
+    rng = np.random.default_rng(0)
+    size = 1.0 / 2000 ** (1 / 3)
+    x = rng.random(3_000_000).astype(np.float32)
+    q32 = np.floor(x / np.float32(size)).astype(np.int64)
+    q64 = np.floor(x.astype(np.float64) / size).astype(np.int64)
+    moved = np.flatnonzero(q32 != q64)
+    assert 0 < moved.size < 50                                     # rare, but there
+    pts = np.stack([x[moved[0]] + np.zeros(4, np.float32), np.linspace(0, 1, 4, dtype=np.float32)], 1)
+    pts = np.concatenate([pts, np.array([[q64[moved[0]] * size + 0.5 * size, 0.0]], np.float32)])     # a point well inside the float64 voxel
+    lab32 = oracle_np.grid_cluster(pts.astype(np.float64), size, label_dtype=np.float32)
+    lab64 = oracle_np.grid_cluster(pts.astype(np.float64), size)
+    assert lab64[0] == lab64[4] and lab32[0] != lab32[4]
+    torch_lab = torch.floor(torch.from_numpy(pts) / size).long()   # what torch does on the float32 tensor
+    assert np.array_equal(torch_lab[:, 0].numpy(), np.floor(pts[:, 0] / np.float32(size)).astype(np.int64))
