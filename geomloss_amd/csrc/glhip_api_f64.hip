@@ -5,9 +5,9 @@
 // by KeOps.  Rounds 1-3 cast them down to fp32 with a warning.  These kernels are the float64 path: soft-min forward and its
 // row gradient (p = 1, 2), kernel product and its row gradient (gaussian / laplacian / energy), dense, batched or block-sparse,
 // for 1 <= D <= 16 (`f64_kernel`) and, since round 5, any larger D (`f64_generic_kernel`).  No matrix cores (there is no fp64 MFMA shape that helps an exp-bound reduction), no expanded form (explicit
-// differences: nothing to cancel), one thread per row, columns staged through LDS as (D + 1) doubles, a running maximum per
-// row.  MI355X retires a float64 `exp` in ~40 VALU instructions, so this path runs at ~4-5e11 pairs/s — 20-25x below the fp32
-// kernels, which is what float64 costs on this part; it exists for callers who need the digits, not the speed.
+// differences: nothing to cancel), 1 to 64 threads per row (small problems spread a row over a wavefront), columns staged through
+// LDS as (D + 1) doubles, a lazy running maximum per row, an inlined 20-instruction `exp` (round 6: see f64_kernel).  It exists for
+// callers who need the digits — the reference's hypothesis suite draws float64 half the time, `geomloss.ot` users land here.
 //
 // The fused entry points (half-step, one-launch iteration, one-pass value + gradient) have no float64 form: the host composes
 // (geomloss_amd/hip.py).  Semantics follow the fp32 kernels: the clamp sqrt(max(d^2, 1e-8)) of utils.py:61 for p = 1 /
@@ -38,12 +38,45 @@ struct F64Params {
 constexpr int kF64Block = 256;
 constexpr int kF64Tile = 128;      // columns per LDS tile: (DMAX + 1) * 128 doubles = 17 KiB at DMAX = 16
 
-// One thread per row.  DMAX = 4 | 16: register arrays of DMAX doubles, loops fully unrolled and predicated on d < D.
-template <int MODE, int DMAX>
+// e^t in double precision without the library call: n = rint(t log2 e), r = t - n ln2 (two-constant reduction, exact to 2^-100),
+// e^r by its Taylor polynomial of degree 13 on |r| <= 0.347 (truncation 3e-18), v_ldexp_f64.  ~20 instructions against ~45 for
+// ocml's exp with its special cases; relative error < 3e-16 (tests/test_f64_gpu.py holds the reductions to 1e-12 of the C oracle).
+// t <= -1100 (and -inf) give 0; NaN propagates; t = +inf is the caller's business (the soft-min rescales before).
+__device__ __forceinline__ double exp_f64(double t) {
+    t = (t < -1100.0) ? -1100.0 : t;
+    const double n = rint(t * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, t);       // ln2_hi (the 33 leading bits: n * ln2_hi is exact)
+    r = fma(-n, 1.90821492927058770002e-10, r);              // ln2_lo
+    double p = 1.0 / 6227020800.0;                            // 1 / 13!
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// TPR threads per row (a power of two <= 64: the threads of a row are lanes of one wavefront).  DMAX = 4 | 16: register arrays of DMAX
+// doubles, loops fully unrolled and predicated on d < D.  Thread `sub` of a row takes the columns sub, sub + TPR, ... of every tile
+// and the partial results meet in a butterfly at the end: 2 000 rows — the coarse level of a two-scale loss, the few hundred points
+// of an `ot.solve_sample` call in float64 — fill the chip with TPR = 64 instead of sitting on 8 of its 256 CUs (round 6).
+// Soft-min: a LAZY running maximum — doubles have the range for it: terms are summed against the maximum known so far and the sum
+// is rescaled only when a term exceeds it by e^500 — so the inner loop has one exponential per pair and no divergent branch to speak of.
+template <int MODE, int DMAX, int TPR>
 __global__ void __launch_bounds__(kF64Block)
 f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
     __shared__ double tile[kF64Tile * (DMAX + 1)];      // [column][D coordinates, scalar]
+    constexpr int kRows = kF64Block / TPR;
     const int tid = threadIdx.x;
+    const int r_in = tid / TPR, sub = tid % TPR;
     const int b = blockIdx.y;
     const bool sparse = n_ranges > 0;
     int row_begin, row_end, q_begin = 0, q_end = 1;
@@ -54,8 +87,8 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
         q_begin = k ? rg.slices_i[k - 1] : 0;
         q_end = rg.slices_i[k];
     } else {
-        row_begin = blockIdx.x * kF64Block;
-        row_end = min(N, row_begin + kF64Block);
+        row_begin = blockIdx.x * kRows;
+        row_end = min(N, row_begin + kRows);
     }
     const double* xb = prm.x + (long)b * N * D;
     const double* yb = prm.y + (long)b * M * D;
@@ -63,8 +96,8 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
     const double inv_eps = 1.0 / prm.scale;
     const double inv_b2 = 1.0 / (prm.scale * prm.scale);
 
-    for (int row0 = row_begin; row0 < row_end; row0 += kF64Block) {
-        const int i = row0 + tid;
+    for (int row0 = row_begin; row0 < row_end; row0 += kRows) {
+        const int i = row0 + r_in;
         const bool live = i < row_end;
         double xi[DMAX];
 #pragma unroll
@@ -85,7 +118,7 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
                 }
                 __syncthreads();
                 if (!live) continue;
-                for (int c = 0; c < n; ++c) {
+                for (int c = sub; c < n; c += TPR) {
                     const double* rec = &tile[c * (DMAX + 1)];
                     double diff[DMAX], d2 = 0.0;
 #pragma unroll
@@ -98,14 +131,15 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
                         const double cost = (prm.p == 2) ? 0.5 * d2 : sqrt(fmax(d2, 1e-8));
                         const double u = sj - cost * inv_eps;
                         if (MODE == F64_SOFTMIN) {
-                            if (u > m) {                      // new maximum: rescale the running sum
-                                ssum = ssum * exp(m - u) + 1.0;
+                            const double t = u - m;
+                            if (t > 500.0) {                  // (also the first finite term: m = -inf) rescale, rare
+                                ssum = ssum * exp_f64(m - u) + 1.0;
                                 m = u;
-                            } else if (u > -INFINITY) {
-                                ssum += exp(u - m);
+                            } else if (u > -INFINITY) {       // (a massless column, h = -inf, adds nothing — also before any mass was seen)
+                                ssum += exp_f64(t);
                             }
                         } else {
-                            const double w = exp(u + fwd_i);  // plan weight: sums to 1 over the row's columns
+                            const double w = exp_f64(u + fwd_i);  // plan weight: sums to 1 over the row's columns
                             const double inv = (prm.p == 2) ? 1.0 : (d2 > 1e-8 ? 1.0 / sqrt(d2) : 0.0);
                             ssum += w;
 #pragma unroll
@@ -113,16 +147,16 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
                         }
                     } else if (MODE == F64_KCONV) {
                         double k;
-                        if (prm.kind == GLHIP_GAUSSIAN) k = exp(-0.5 * d2 * inv_b2);
-                        else if (prm.kind == GLHIP_LAPLACIAN) k = exp(-sqrt(fmax(d2 * inv_b2, 1e-8)));
+                        if (prm.kind == GLHIP_GAUSSIAN) k = exp_f64(-0.5 * d2 * inv_b2);
+                        else if (prm.kind == GLHIP_LAPLACIAN) k = exp_f64(-sqrt(fmax(d2 * inv_b2, 1e-8)));
                         else k = -sqrt(fmax(d2, 1e-8));
                         ssum = fma(k, sj, ssum);
                     } else {
                         double coef;                          // d k / d x = coef * (x - y)
-                        if (prm.kind == GLHIP_GAUSSIAN) coef = -exp(-0.5 * d2 * inv_b2) * inv_b2;
+                        if (prm.kind == GLHIP_GAUSSIAN) coef = -exp_f64(-0.5 * d2 * inv_b2) * inv_b2;
                         else if (prm.kind == GLHIP_LAPLACIAN) {
                             const double dist = sqrt(d2);
-                            coef = (d2 * inv_b2 > 1e-8) ? -exp(-dist / prm.scale) / (prm.scale * dist) : 0.0;
+                            coef = (d2 * inv_b2 > 1e-8) ? -exp_f64(-dist / prm.scale) / (prm.scale * dist) : 0.0;
                         } else coef = (d2 > 1e-8) ? -1.0 / sqrt(d2) : 0.0;
 #pragma unroll
                         for (int d = 0; d < DMAX; ++d) acc[d] = fma(sj * coef, diff[d], acc[d]);
@@ -130,7 +164,23 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
                 }
             }
         }
-        if (!live) continue;
+        // the TPR partial results of a row: butterfly over its lanes (every lane of the wavefront takes part; dead rows carry neutral values)
+        if constexpr (TPR > 1) {
+#pragma unroll
+            for (int off = TPR / 2; off > 0; off >>= 1) {
+                if (MODE == F64_SOFTMIN) {
+                    const double m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(ssum, off, 64);
+                    const double mm = fmax(m, m2);
+                    if (mm > -INFINITY) ssum = ssum * exp_f64(m - mm) + s2 * exp_f64(m2 - mm);
+                    m = mm;
+                } else {
+                    ssum += __shfl_xor(ssum, off, 64);
+#pragma unroll
+                    for (int d = 0; d < DMAX; ++d) acc[d] += __shfl_xor(acc[d], off, 64);
+                }
+            }
+        }
+        if (!live || sub != 0) continue;
         const long idx = (long)b * N + i;
         if (MODE == F64_SOFTMIN) {
             prm.out[idx] = (m > -INFINITY) ? -prm.scale * (m + log(ssum)) : INFINITY;      // empty / massless row: -eps * (-inf)
@@ -275,11 +325,21 @@ int launch_f64(const char* fn, const F64Params& prm, const int32_t* ri, const in
     if (B == 0 || N == 0) return GLHIP_OK;
     if (!prm.x || !prm.out || ((!prm.y || !prm.s) && M > 0)) return fail(GLHIP_EINVAL, "%s: NULL pointer", fn);
     const Ranges rg{ri, si, rj, nullptr};
-    const dim3 grid(n_ranges > 0 ? n_ranges : (N + kF64Block - 1) / kF64Block, B, 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (D <= 4) hipLaunchKernelGGL((f64_kernel<MODE, 4>), grid, dim3(kF64Block), 0, st, prm, rg, n_ranges, N, M, D);
-    else if (D <= 16) hipLaunchKernelGGL((f64_kernel<MODE, 16>), grid, dim3(kF64Block), 0, st, prm, rg, n_ranges, N, M, D);
-    else {
+    if (D <= 16) {
+        // threads per row: enough of them to put ~4 wavefronts on every SIMD (256 CUs x 4 SIMDs x 4 x 64 lanes), while every thread
+        // keeps at least 4 columns of a 128-column tile; block-sparse launches: also no wider than their row blocks are tall
+        const long rows = (long)B * N;
+        int tpr = 1;
+        while (tpr < 64 && rows * tpr < 262144 && (long)M >= 8L * tpr) tpr *= 4;
+        if (n_ranges > 0) while (tpr > 1 && (long)(kF64Block / tpr) * n_ranges < N) tpr /= 4;
+#define GL_F64(DM, T) hipLaunchKernelGGL((f64_kernel<MODE, DM, T>), dim3(n_ranges > 0 ? n_ranges : (N + kF64Block / T - 1) / (kF64Block / T), B, 1), \
+                                         dim3(kF64Block), 0, st, prm, rg, n_ranges, N, M, D)
+        if (D <= 4) { if (tpr == 1) GL_F64(4, 1); else if (tpr == 4) GL_F64(4, 4); else if (tpr == 16) GL_F64(4, 16); else GL_F64(4, 64); }
+        else { if (tpr == 1) GL_F64(16, 1); else if (tpr == 4) GL_F64(16, 4); else if (tpr == 16) GL_F64(16, 16); else GL_F64(16, 64); }
+#undef GL_F64
+    } else {
+        const dim3 grid(n_ranges > 0 ? n_ranges : (N + kF64Block - 1) / kF64Block, B, 1);
         int tile_cols = (int)(32768 / ((size_t)(D + 1) * sizeof(double)));      // <= 32 KiB of LDS per workgroup
         tile_cols = tile_cols < 1 ? 1 : (tile_cols > kF64Tile ? kF64Tile : tile_cols);
         const size_t lds = (size_t)tile_cols * (D + 1) * sizeof(double);

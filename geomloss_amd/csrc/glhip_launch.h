@@ -122,14 +122,13 @@ void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, c
     else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
 
-template <int D, typename T, int KIND, int NW, int L = XL_BF16X3, int RT = 1>
+template <int D, typename T, int KIND, int NW, int L = XL_BF16X3>
 void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n_ranges, int B, int N, int M,
                             const Scratch& sc, hipStream_t st) {
     static_assert(L == XL_BF16X3 || KIND == FWD_X32, "the f16 x 2 layout exists on the 32x32x16 kernel only");
-    static_assert(RT == 1 || (KIND == FWD_X32 && NW == 4), "two row tiles per wavefront: block-sparse pre-packed launches of the 32x32x16 kernel");
     constexpr int NR = X32Layout<L>::NR;
     using MergeOp = SoftminFwdOp<D, 2, false, 1, T>;   // the forward merge does not use the row-pass centre
-    constexpr int kRowsPerBlock = NW * 32 * RT;        // 16 * kFwdRT = 32 rows per wavefront in all three kernels (x RT row tiles, x32 only)
+    constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
     static_assert(kFwdRT == 2, "row tiling of the forward kernels");
     unsigned chunk_grid = 0;   // block-sparse: one workgroup per row chunk of kRowsPerBlock rows (build_row_chunks_kernel)
     const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid) : rg;
@@ -197,11 +196,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     if (n_ranges > 0) {
         if (plan_pre(sp.n_splits)) {
             pack();
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, RT, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
-        } else if constexpr (RT == 1) {
-            launch_fwd_kernel<D, T, KIND, NW, true, L>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
+            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, 1, NW, true, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, pk);
         } else {
-            hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, true, RT, NW, false, L>), dim3(chunk_grid, 1, sp.n_splits), dim3(NW * 64), 0, st, prm, rgc, N, M, sp, PackedCols{nullptr, 0});
+            launch_fwd_kernel<D, T, KIND, NW, true, L>(dim3(chunk_grid, 1, sp.n_splits), st, prm, rgc, N, M, sp);
         }
         if (sp.n_splits > 1)
             hipLaunchKernelGGL((merge_kernel<MergeOp, true>), dim3(n_ranges, 1, 1), dim3(kBlock), 0, st, prm, rg, N, sp);
@@ -229,14 +226,11 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
     static const int forced_nw = getenv("GLHIP_FWD_NW") ? atoi(getenv("GLHIP_FWD_NW")) : 0;   // tuning knob (4 or 8)
     if constexpr (KIND == FWD_X32) {
         if (sc.h2) {      // GLHIP_FLAG_F16X2: the same kernel on the f16 x 2 layout (one MFMA per block); same workgroup shapes
-            static const int forced_rt = getenv("GLHIP_FWD_RT") ? atoi(getenv("GLHIP_FWD_RT")) : 0;   // tuning knob (1 or 2)
-            const bool big_blocks = n_ranges > 0 && (double)B * N * M >= 5e8 && N / n_ranges >= 192;
-            if (n_ranges > 0 && sc.small_rows && !forced_nw) launch_softmin_mfma_nw<D, T, FWD_X32, 2, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
-            else if (big_blocks && forced_rt == 2 && !forced_nw)
-                // block-sparse, row blocks of hundreds of points: 4 wavefronts x 2 row tiles — the same 256 rows per workgroup, each column
-                // record read from LDS once for two 32 x 32 blocks
-                launch_softmin_mfma_nw<D, T, FWD_X32, 4, XL_F16X2, 2>(prm, rg, n_ranges, B, N, M, sc, st);
-            else if (forced_nw ? forced_nw == 8 : ((double)B * N * M >= 5e8 && (n_ranges == 0 ? (long)B * N >= 32768 : N / n_ranges >= 192)))
+            // f16 x 2 (16 KB tiles): block-sparse launches run 4-wavefront workgroups whatever the cluster size — at N = 1e6 (clusters of
+            // ~455 rows) 236 ms per two-scale loss against 241 with 8 wavefronts and 297 with 2 (round 6; with 32-KB bf16 x 3 tiles
+            // 8 wavefronts won: the rule below); 2 x 2 row tiles per wavefront and 2 .. 12 column splits made no difference
+            if (n_ranges > 0 && ((sc.small_rows && !forced_nw) || forced_nw == 2)) launch_softmin_mfma_nw<D, T, FWD_X32, 2, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
+            else if (forced_nw ? forced_nw == 8 : (n_ranges == 0 && (double)B * N * M >= 5e8 && (long)B * N >= 32768))
                 launch_softmin_mfma_nw<D, T, FWD_X32, 8, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
             else launch_softmin_mfma_nw<D, T, FWD_X32, 4, XL_F16X2>(prm, rg, n_ranges, B, N, M, sc, st);
             return;
@@ -272,15 +266,6 @@ void launch_wsum_kernel(bool x32, bool pre, dim3 grid, hipStream_t st, const Wsu
     if constexpr (wsum_uses_x32<MODE>()) {
         if (x32 && pre) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
         if (x32) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, false>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
-    }
-    if constexpr (MODE == WS_SOFTMIN_BWD) {
-        // long column runs: re-based moments (glhip_wsum_mfma.h) — the rounding of M / 16 additions at the size of the row's offset
-        // from the workgroup centre is what limited the same-law gradients at N = 1e6
-        static const long rebase_min = getenv("GLHIP_REBASE_MIN") ? atol(getenv("GLHIP_REBASE_MIN")) : 8192;
-        if ((long)M >= rebase_min) {
-            hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
-            return;
-        }
     }
     hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
@@ -982,6 +967,8 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
             // 1e6 x 1e6, 36.8 -> 35.0 ms per online loss at 1e5; batches of 4096 x 4096 problems lose 4 % to the x32 kernel's staging
             // (B = 256: 16.2 -> 17.0 ms per loss), and block-sparse launches keep the gathered pre-packed tiles of glhip_softmin_x32.h.
             static const bool via_xd = getenv("GLHIP_H2_VIA_XD") ? atoi(getenv("GLHIP_H2_VIA_XD")) != 0 : true;      // A/B knob
+            // (block-sparse launches through this kernel, packing their tiles on the fly in 512-row workgroups: 281 vs 244 ms per two-scale
+            // loss at 1e6, round 6)
             if (via_xd && p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {
                 if (D == 1) launch_xd_l<XD_SOFTMIN, 1, T, SoftminFwdOp<1, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
                 else if (D == 2) launch_xd_l<XD_SOFTMIN, 2, T, SoftminFwdOp<2, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);

@@ -253,7 +253,11 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         if (PRE) launch_centre<D, T>(prm.x, b, N, centre);
         else load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
-        const int wave_row0 = row0 + wave * kRowsPerWave;
+        // block-sparse: the row chunks of a cluster of ~455 points are 256 + 199 rows, so one wavefront in sixteen owns no row —
+        // always the last one, i.e. always the same SIMD of its CU.  Rotating the wavefront -> rows assignment by the chunk index
+        // spreads those empty slots over the four SIMDs.
+        const int wslot = SPARSE ? ((wave + bx) & (NW - 1)) : wave;
+        const int wave_row0 = row0 + wslot * kRowsPerWave;
         uint4 Xlo[RT], Xhi[RT];
         float m[RT], ssum[RT];
 #pragma unroll

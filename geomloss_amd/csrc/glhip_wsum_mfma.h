@@ -60,23 +60,13 @@ template <int MODE, int D> struct WsumShape {
     static constexpr int kPart = (MODE == WS_SOFTMIN_BWD || MODE == WS_GAUSS_FWDGRAD) ? D + 1 : (MODE == WS_GAUSS_FWD ? 1 : D);
 };
 
-// REBASE (soft-min gradient over long column runs): the barycentre sum_j P_ij y_j is wanted RELATIVE TO x_i — the gradient is
-// x_i - ybar_i, and for two samples of one law the two gradients of a debiased loss cancel to 1e-3 of a blur — but the first
-// moments are accumulated relative to the workgroup's centre, so their partial sums are of size |x_i - c| S0 and every one of the
-// M / 16 float32 additions of a lane rounds at that size: 2^-24 |x_i - c| sqrt(M / 16) = 5e-7 on a barycentre at M = 2e5 kept
-// columns, 1.5e-4 of the gradient's max-norm on BASELINE config 3 (round 6, seed 2: the test failed).  Here the moments are
-// re-based after every tile: the tile's mass is accumulated apart, and R_d <- R_d - xt_d m_tile keeps R_d = S1_d - xt_d S0 — of
-// the size of the ANSWER — as the running quantity; what is left is the rounding inside one tile (32 additions, weighted by
-// that tile's mass).  Cost: 16 registers, ~100 instructions per tile of 512 columns (4 %).
-template <int MODE, int D, typename T, bool SPARSE, bool REBASE = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REBASE && SPARSE ? 3 : 1)))      // (3 waves / SIMD kept: <= 168 VGPRs)
+template <int MODE, int D, typename T, bool SPARSE>
+__global__ void __launch_bounds__(kBlock)
 wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
-    static_assert(!REBASE || MODE == WS_SOFTMIN_BWD, "re-based moments: the soft-min gradient");
     constexpr int NQ = WsumShape<MODE, D>::kNQ;
     constexpr int NA = WsumShape<MODE, D>::kNA;
     __shared__ uint4 tileX[(kTileX / 16) * 64];          // bf16 x 3 B operands, as in softmin_fwd_xdl_kernel
     __shared__ f32x4 tileQ[NQ * (kTileX / 64) * 16];
-    __shared__ f32x4 rowX[REBASE ? kMfmaRowsPerBlock : 1];   // REBASE: x_i - centre of the workgroup's rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,18 +94,6 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         uint4 A[kMfmaRT];
         f32x4 Cop[kMfmaRT];                // per-row constant added to every exponent
         f32x4 acc[kMfmaRT][NA];
-        f32x4 tmass[REBASE ? kMfmaRT : 1]; // REBASE: the mass of the current tile
-        if constexpr (REBASE) {
-            __syncthreads();               // (the previous row pass is done with rowX)
-            float xi[D];
-            load_point<D, T>(prm.x, (long)b * N + min(row0 + tid, row_end - 1), xi);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < D; ++d) v[d] = xi[d] - centre[d];
-            rowX[tid] = v;                 // read after the barriers of the first tile
-#pragma unroll
-            for (int rt = 0; rt < kMfmaRT; ++rt) tmass[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int rt = 0; rt < kMfmaRT; ++rt) {
             const int i = min(wave_row0 + rt * 16 + lj, row_end - 1);
@@ -206,25 +184,11 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                             if (MODE == WS_SOFTMIN_BWD) {
 #pragma unroll
                                 for (int d = 0; d < D; ++d) fma4(acc[rt][d], w, Q[d][g]);
-                                if constexpr (REBASE) tmass[rt] += w;
-                                else acc[rt][D] += w;
+                                acc[rt][D] += w;
                             } else {
 #pragma unroll
                                 for (int c = 0; c < NQ; ++c) fma4(acc[rt][c], w, Q[c][g]);
                             }
-                        }
-                    }
-                }
-                if constexpr (REBASE) {      // R_d <- R_d - xt_d m_tile; S0 <- S0 + m_tile
-#pragma unroll
-                    for (int rt = 0; rt < kMfmaRT; ++rt) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const f32x4 xr = rowX[wave * kMfmaRowsPerWave + rt * 16 + lk * 4 + r];
-#pragma unroll
-                            for (int d = 0; d < D; ++d) acc[rt][d][r] = __builtin_fmaf(-xr[d], tmass[rt][r], acc[rt][d][r]);
-                            acc[rt][D][r] += tmass[rt][r];
-                            tmass[rt][r] = 0.f;
                         }
                     }
                 }
@@ -265,13 +229,12 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
                                     const float gi = prm.g ? prm.g[(long)b * N + i] : 1.f;
                                     const float inv = (a_[D] > 0.f) ? 1.0f / a_[D] : 0.f;
 #pragma unroll
-                                    for (int d = 0; d < D; ++d)      // REBASE: a_[d] = S1_d - xt_d S0 already
-                                        prm.gx[((long)b * N + i) * D + d] = REBASE ? gi * (-a_[d] * inv) : gi * (xt[d] - a_[d] * inv);
+                                    for (int d = 0; d < D; ++d) prm.gx[((long)b * N + i) * D + d] = gi * (xt[d] - a_[d] * inv);
                                     if (prm.out)   // value-and-gradient mode: the mass turns the guess into the exact soft-min
                                         prm.out[(long)b * N + i] = prm.fwd[(long)b * N + i] + prm.out_scale * (prm.tscale + fast_log2(a_[D]));
-                                } else {     // (partials stay in the additive (S1, S0) format of the merge: ONE rounding at size |xt| S0 per split)
+                                } else {
 #pragma unroll
-                                    for (int c = 0; c < NA; ++c) part[c] = (REBASE && c < D) ? __builtin_fmaf(xt[c], a_[D], a_[c]) : a_[c];
+                                    for (int c = 0; c < NA; ++c) part[c] = a_[c];
                                 }
                             } else if (MODE == WS_GAUSS_FWD) {
                                 if (ns == 1) prm.out[(long)b * N + i] = a_[0];

@@ -255,6 +255,7 @@ class _HipSoftmin:
 # Opt-in (GEOMLOSS_HIP_GRAPH=1 or set_graph_mode(True)) and only when `diameter` is given, because the temperatures are
 # kernel arguments baked into the graph: a data-dependent diameter would force a new capture for every input.
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
+_COARSE_F64_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_COARSE_F64_MIN_PAIRS", "1e11"))   # two-scale losses: float64 coarse level from here on
 _F16X2 = os.environ.get("GEOMLOSS_HIP_F16X2", "1") != "0"      # f16 x 2 exponents where the temperature allows (_HipSoftmin.set_range)
 _anneal_in_library = os.environ.get("GEOMLOSS_HIP_ANNEAL", "1") != "0"   # the iterations of a level queued by one library call (A/B knob)
 _fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
@@ -584,6 +585,13 @@ def sinkhorn_multiscale(
                 )
             )
 
+    if float(N) * y.shape[0] >= _COARSE_F64_MIN_PAIRS and x_c.dtype == torch.float32:
+        # The coarse level of a big problem runs in float64.  Two samples of one law at N = 1e6 leave a gradient of 1e-3 of a blur and a
+        # loss of 1e-4 of its terms, and the float32 rounding of the coarse trajectory (potentials of size 1 at the first temperatures:
+        # 1e-7 per cluster and iteration) reaches them through the nearly undamped mode (f + c(x), g - c(y)): dL/dx was 4e-5 .. 6e-5 of
+        # its max-norm from the float64 oracle (profiles/r06_full_size_parity.txt).  ~2000 clusters: 36 float64 soft-mins of 35 us
+        # (glhip_api_f64.hip spreads their rows over wavefronts) plus their torch arithmetic, < 1 % of such a loss.
+        a_c, b_c, x_c, y_c = a_c.double(), b_c.double(), x_c.double(), y_c.double()
     la_c, la, lb_c, lb = log_weights_many([a_c, a, b_c, b])
     a_logs, b_logs = [la_c, la], [lb_c, lb]
     if debias:
