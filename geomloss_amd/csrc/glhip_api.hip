@@ -1,5 +1,6 @@
 // glhip_api.hip — C-ABI of libgeomloss_hip.so (include/glhip.h), part 1: version / errors / scratch size and the soft-min FORWARD family
 // (glhip_softmin_fwd, glhip_sinkhorn_step, glhip_sinkhorn_iter4, glhip_sinkhorn_anneal, glhip_sinkhorn_extrapolate4).  gfx950 only.
+#include "glhip_autosort.h"
 #include "glhip_launch.h"
 
 namespace glhip {
@@ -81,6 +82,12 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges) {
         bytes = bytes > ws ? bytes : ws;
     }
     if (n_ranges > 0) bytes += chunk_table_bytes(n_ranges, N, 64);   // row-chunk table of block-sparse launches (64-row tiles: the smallest, GLHIP_FLAG_SMALL_ROW_BLOCKS)
+    if (autosort_applies(B, N, M, D, n_ranges, 0)) {
+        // big dense distance reductions (p = 1, laplacian, energy) sort their clouds inside the workspace and run as a block-sparse launch
+        // over slabs of 256 rows (glhip_autosort.h): the sorted copies + what that inner launch asks for
+        const size_t sorted = autosort_bytes(N, M, D) + glhip_workspace_bytes(1, N, M, D, (N + kSortSlab - 1) / kSortSlab);
+        bytes = bytes > sorted ? bytes : sorted;
+    }
     return bytes;
 }
 
@@ -98,6 +105,20 @@ int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out, 
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p == 1 && autosort_applies(B, N, M, D, n_ranges, flags)) {      // glhip_autosort.h: compact row blocks -> distances on the matrix cores
+        AutoSort a;
+        const int C = (N + kSortSlab - 1) / kSortSlab;
+        rc = autosort_prepare(a, x, y, N, M, D, in_dtype, workspace, workspace_bytes, glhip_workspace_bytes(1, N, M, D, C), st);
+        if (rc) return rc;
+        if (a.on) {
+            gather_f32(h, a.perm_y, a.col0, M, st);
+            rc = glhip_softmin_fwd(a.xs, a.ys, a.col0, a.out, 1, N, M, D, eps, p, in_dtype, a.ranges_i, a.slices_i, a.red, a.C, a.inner_ws,
+                                   a.inner_bytes, flags | GLHIP_FLAG_MFMA_DIST | GLHIP_FLAG_NO_SORT, stream);
+            if (rc) return rc;
+            scatter_f32(a.out, a.perm_x, out, N, st);
+            return check_launch("glhip_softmin_fwd");
+        }
+    }
     const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     rc = (in_dtype == GLHIP_F32)
              ? softmin_typed<false, float>(x, y, h, out, nullptr, nullptr, nullptr, B, N, M, D, eps, p, rg, n_ranges, sc, flags, st)
@@ -118,6 +139,22 @@ int glhip_sinkhorn_step(const void* x, const void* y, const float* logw, const f
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step: p must be 1 or 2 (got %d)", p);
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p == 1 && autosort_applies(B, N, M, D, n_ranges, flags)) {      // as glhip_softmin_fwd; the potentials travel with their clouds
+        AutoSort a;
+        const int C = (N + kSortSlab - 1) / kSortSlab;
+        rc = autosort_prepare(a, x, y, N, M, D, in_dtype, workspace, workspace_bytes, glhip_workspace_bytes(1, N, M, D, C), st);
+        if (rc) return rc;
+        if (a.on) {
+            gather_f32(logw, a.perm_y, a.col0, M, st);
+            if (pot) gather_f32(pot, a.perm_y, a.col1, M, st);
+            if (prev) gather_f32(prev, a.perm_x, a.row0, N, st);
+            rc = glhip_sinkhorn_step(a.xs, a.ys, a.col0, pot ? a.col1 : nullptr, prev ? a.row0 : nullptr, a.out, 1, N, M, D, eps, damping, p, in_dtype,
+                                     a.ranges_i, a.slices_i, a.red, a.C, a.inner_ws, a.inner_bytes, flags | GLHIP_FLAG_MFMA_DIST | GLHIP_FLAG_NO_SORT, stream);
+            if (rc) return rc;
+            scatter_f32(a.out, a.perm_x, out, N, st);
+            return check_launch("glhip_sinkhorn_step");
+        }
+    }
     const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     StepArgs step;
     step.pot = pot;

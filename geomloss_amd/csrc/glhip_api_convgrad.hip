@@ -1,4 +1,5 @@
 // glhip_api_convgrad.hip — C-ABI part 4: gradients of the kernel products.
+#include "glhip_autosort.h"
 #include "glhip_launch.h"
 
 extern "C" {
@@ -38,6 +39,21 @@ int glhip_kernel_conv_fwd_grad(int kind, const void* x, const void* y, const flo
     if (kind != GLHIP_ENERGY && !(blur > 0.f)) return fail(GLHIP_EINVAL, "glhip_kernel_conv_fwd_grad: blur must be > 0");
     const Ranges rg{ranges_i, slices_i, redranges_j};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (kind != GLHIP_GAUSSIAN && autosort_applies(B, N, M, D, n_ranges, flags)) {      // as glhip_kernel_conv_fwd (glhip_autosort.h)
+        AutoSort a;
+        const int C = (N + kSortSlab - 1) / kSortSlab;
+        rc = autosort_prepare(a, x, y, N, M, D, in_dtype, workspace, workspace_bytes, glhip_workspace_bytes(1, N, M, D, C), st);
+        if (rc) return rc;
+        if (a.on) {
+            gather_f32(v, a.perm_y, a.col0, M, st);
+            rc = glhip_kernel_conv_fwd_grad(kind, a.xs, a.ys, a.col0, a.out, a.out_rows, 1, N, M, D, blur, in_dtype, a.ranges_i, a.slices_i, a.red, a.C,
+                                            a.inner_ws, a.inner_bytes, flags | GLHIP_FLAG_MFMA_DIST | GLHIP_FLAG_NO_SORT, stream);
+            if (rc) return rc;
+            scatter_f32(a.out, a.perm_x, out, N, st);
+            scatter_f32(a.out_rows, a.perm_x, grad_unit, N, st, D);
+            return check_launch("glhip_kernel_conv_fwd_grad");
+        }
+    }
     const Scratch sc = make_scratch(workspace, workspace_bytes, flags, n_ranges, N);
     auto run = [&](auto tag) {
         using T = decltype(tag);

@@ -14,6 +14,7 @@
 #include <climits>
 #include <cstdint>
 
+#include "glhip_autosort.h"
 #include "glhip_common.h"
 #include "glhip_error.h"
 
@@ -229,6 +230,201 @@ int grid_cluster_typed(const void* x_, const float* w, int N, int D, float pre_d
         hipLaunchKernelGGL((gather_kernel<T>), dim3(blocks), dim3(256), 0, st, x, w, perm, N, D, static_cast<T*>(x_sorted), w_sorted);
     return check_launch("glhip_grid_cluster");
 }
+
+// ---- compact order of a cloud (glhip_autosort.h): bounding box -> voxel edge -> boustrophedon path keys -> radix sort -> gather ----
+
+struct SortHead {           // first bytes of the sort scratch
+    unsigned lo[3], hi[3];  // bounding box, as order-preserving unsigned images of the floats
+    float voxel;
+    int qmin[3], ext[3];
+};
+
+__device__ __forceinline__ unsigned ordered_of(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_of(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__global__ void sort_head_init_kernel(SortHead* head) {
+    const int t = threadIdx.x;
+    if (t < 3) { head->lo[t] = 0xFFFFFFFFu; head->hi[t] = 0u; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bbox_kernel(const T* __restrict__ x, int n, int D, SortHead* head) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        for (int d = 0; d < D; ++d) {
+            const float v = to_f32<T>(x[i * D + d]);
+            lo[d] = fminf(lo[d], v);
+            hi[d] = fmaxf(hi[d], v);
+        }
+    }
+    for (int d = 0; d < D; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    }
+    __shared__ float wlo[4][3], whi[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < D; ++d) { wlo[wave][d] = lo[d]; whi[wave][d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float l = wlo[0][d], h = whi[0][d];
+        for (int w = 1; w < 4; ++w) { l = fminf(l, wlo[w][d]); h = fmaxf(h, whi[w][d]); }
+        if (l <= h) {
+            atomicMin(&head->lo[d], ordered_of(l));
+            atomicMax(&head->hi[d], ordered_of(h));
+        }
+    }
+}
+
+// voxel edge that puts ~rows_per_voxel points in an occupied voxel (hip.py:_voxel_for), and the voxel grid of the cloud
+__global__ void voxel_kernel(SortHead* head, int n, int D, int rows_per_voxel) {
+    if (threadIdx.x != 0) return;
+    float lo[3], ext[3], emax = 0.f;
+    for (int d = 0; d < D; ++d) {
+        lo[d] = float_of(head->lo[d]);
+        ext[d] = float_of(head->hi[d]) - lo[d];
+        emax = fmaxf(emax, ext[d]);
+    }
+    float vol = 1.f;
+    int live = 0;
+    for (int d = 0; d < D; ++d)
+        if (ext[d] > 1e-6f * fmaxf(emax, 1e-30f)) { vol *= ext[d]; ++live; }
+    float voxel = powf(vol * (float)rows_per_voxel / (float)n, 1.0f / (float)(live > 0 ? live : 1));
+    voxel = fmaxf(fmaxf(voxel, emax / (float)(1 << 20)), 1e-30f);       // never more than 2^20 voxels along an axis
+    head->voxel = voxel;
+    for (int d = 0; d < 3; ++d) {
+        head->qmin[d] = d < D ? (int)floorf(lo[d] / voxel) : 0;
+        head->ext[d] = d < D ? (int)floorf((lo[d] + ext[d]) / voxel) - head->qmin[d] + 1 : 1;
+    }
+}
+
+// sort key = index of the point's voxel along a boustrophedon path through the voxel grid (the scan direction of an axis flips each
+// time the path index of the axes before it advances): voxels that follow each other in the order are face neighbours in space, so
+// ANY run of consecutive rows of the sorted cloud is spatially compact (hip.py:_serpentine did this on the cluster list)
+template <typename T>
+__global__ void __launch_bounds__(256) path_keys_kernel(const T* __restrict__ x, int n, int D, const SortHead* __restrict__ head,
+                                                        uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float voxel = head->voxel;
+    uint64_t path = 0;
+    for (int d = 0; d < D; ++d) {
+        const int e = head->ext[d];
+        int q = (int)floorf(to_f32<T>(x[i * D + d]) / voxel) - head->qmin[d];
+        q = q < 0 ? 0 : (q >= e ? e - 1 : q);
+        const int c = (path & 1) ? e - 1 - q : q;
+        path = path * (uint64_t)e + (uint64_t)c;
+    }
+    keys[i] = path;
+    idx[i] = (int32_t)i;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gather_points_kernel(const T* __restrict__ x, const int32_t* __restrict__ perm, int n, int D, T* __restrict__ xs) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const long j = perm[p];
+    for (int d = 0; d < D; ++d) xs[p * D + d] = x[j * D + d];
+}
+
+__global__ void __launch_bounds__(256) gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, float* __restrict__ dst, int n) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) dst[k] = src[perm[k]];
+}
+__global__ void __launch_bounds__(256) scatter_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, float* __restrict__ dst, int n, int width) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const long j = perm[k];
+    for (int d = 0; d < width; ++d) dst[j * width + d] = src[k * width + d];
+}
+
+// "every slab of kSortSlab rows x all columns, in kSortColChunks column intervals" as KeOps-style ranges
+__global__ void __launch_bounds__(256) slab_ranges_kernel(int N, int M, int C, int32_t* __restrict__ ranges_i, int32_t* __restrict__ slices_i,
+                                                          int32_t* __restrict__ red) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= C) return;
+    ranges_i[2 * k] = k * kSortSlab;
+    ranges_i[2 * k + 1] = min(N, (k + 1) * kSortSlab);
+    slices_i[k] = (k + 1) * kSortColChunks;
+    const int step = (((M + kSortColChunks - 1) / kSortColChunks) + 31) / 32 * 32;
+    for (int c = 0; c < kSortColChunks; ++c) {
+        red[2 * (k * kSortColChunks + c)] = min(M, c * step);
+        red[2 * (k * kSortColChunks + c) + 1] = min(M, (c + 1) * step);
+    }
+}
+
+size_t sort64_temp_bytes(int n) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    int32_t* v = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, 64u, (hipStream_t)0) != hipSuccess || bytes == 0)
+        bytes = (size_t)n * 16 + (1 << 20);
+    (void)hipGetLastError();
+    return bytes;
+}
+
+template <typename T>
+int compact_sort_typed(const void* z_, int n, int D, int rows_per_voxel, int32_t* perm, void* z_sorted, void* scratch, size_t scratch_bytes,
+                       hipStream_t st) {
+    const T* z = static_cast<const T*>(z_);
+    char* ws = static_cast<char*>(scratch);
+    SortHead* head = reinterpret_cast<SortHead*>(ws);
+    size_t off = align256(sizeof(SortHead));
+    uint64_t* keys_in = reinterpret_cast<uint64_t*>(ws + off); off += align256((size_t)n * 8);
+    uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + off); off += align256((size_t)n * 8);
+    int32_t* idx_in = reinterpret_cast<int32_t*>(ws + off); off += align256((size_t)n * 4);
+    size_t temp = sort64_temp_bytes(n);
+    if (off + temp > scratch_bytes) return fail(GLHIP_EINVAL, "compact_sort: scratch of %zu bytes, need %zu", scratch_bytes, off + temp);
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(sort_head_init_kernel, dim3(1), dim3(64), 0, st, head);
+    hipLaunchKernelGGL((bbox_kernel<T>), dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, z, n, D, head);
+    hipLaunchKernelGGL(voxel_kernel, dim3(1), dim3(64), 0, st, head, n, D, rows_per_voxel);
+    hipLaunchKernelGGL((path_keys_kernel<T>), dim3(blocks), dim3(256), 0, st, z, n, D, head, keys_in, idx_in);
+    if (rocprim::radix_sort_pairs(ws + off, temp, keys_in, keys_out, idx_in, perm, (size_t)n, 0u, 64u, st) != hipSuccess)
+        return fail(GLHIP_ELAUNCH, "compact_sort: radix sort failed: %s", hipGetErrorString(hipGetLastError()));
+    hipLaunchKernelGGL((gather_points_kernel<T>), dim3(blocks), dim3(256), 0, st, z, perm, n, D, static_cast<T*>(z_sorted));
+    return GLHIP_OK;
+}
+
+}  // namespace
+
+namespace glhip {
+
+size_t compact_sort_scratch_bytes(int n) {
+    return align256(sizeof(SortHead)) + 2 * align256((size_t)n * 8) + align256((size_t)n * 4) + align256(sort64_temp_bytes(n));
+}
+
+int compact_sort(const void* z, int n, int D, int in_dtype, int rows_per_voxel, int32_t* perm, void* z_sorted, void* scratch,
+                 size_t scratch_bytes, hipStream_t st) {
+    return in_dtype == GLHIP_F32 ? compact_sort_typed<float>(z, n, D, rows_per_voxel, perm, z_sorted, scratch, scratch_bytes, st)
+                                 : compact_sort_typed<bf16_t>(z, n, D, rows_per_voxel, perm, z_sorted, scratch, scratch_bytes, st);
+}
+
+void gather_f32(const float* src, const int32_t* perm, float* dst, int n, hipStream_t st) {
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, perm, dst, n);
+}
+
+void scatter_f32(const float* src, const int32_t* perm, float* dst, int n, hipStream_t st, int width) {
+    hipLaunchKernelGGL(scatter_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, perm, dst, n, width);
+}
+
+void slab_ranges(int N, int M, int32_t* ranges_i, int32_t* slices_i, int32_t* red, hipStream_t st) {
+    const int C = (N + kSortSlab - 1) / kSortSlab;
+    hipLaunchKernelGGL(slab_ranges_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, M, C, ranges_i, slices_i, red);
+}
+
+}  // namespace glhip
+
+namespace {
 
 // ---- keep rule -> merged column intervals ------------------------------------------------------------------------------
 

@@ -23,6 +23,7 @@ KERNEL_KINDS = {"gaussian": GAUSSIAN, "laplacian": LAPLACIAN, "energy": ENERGY}
 F32, BF16 = 0, 1
 FLAG_DIRECT, FLAG_NO_MFMA, FLAG_NO_SPLIT, FLAG_F32_MFMA, FLAG_XDL16, FLAG_PREPACK, FLAG_MFMA_DIST, FLAG_SMALL_ROW_BLOCKS = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_F16X2 = 256                # exponents from two f16 pieces per coordinate; the caller vouches for the range (glhip.h)
+FLAG_NO_SORT = 512              # big dense distance reductions: do not voxel-sort the clouds inside the library (glhip.h)
 FLAG_GRAD_FAMILY = FLAG_XDL16   # kernel products rounded like the product-and-gradient kernel of the same kind (glhip.h)
 XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussian product run on the matrix cores up to this dimension
 
@@ -565,7 +566,7 @@ def _serpentine(perm, xs, ranges, cents, voxel):
     """Re-orders the voxel clusters of a lexicographically voxel-sorted cloud along a boustrophedon path (the scan direction of
     every axis flips each time the path index of the axes before it advances), so that voxels that follow each other in memory
     are always face neighbours in space.  ANY run of consecutive rows of the result is then spatially compact — which is what
-    lets :class:`_CompactRows` cut the rows into equal slabs instead of one (unevenly filled) block per voxel.
+    lets the callers cut the rows into equal slabs instead of one (unevenly filled) block per voxel.
     perm (N,) int64, xs (N,D) sorted cloud, ranges (C,2), cents (C,D) -> (perm, xs) in the new order."""
     q = torch.floor(cents.float() / voxel).long()
     q = q - q.amin(0)
@@ -591,83 +592,17 @@ def compact_order(x, rows_per_voxel=None):
     return _serpentine(perm.long(), xs, ranges, cents, voxel)
 
 
-class _CompactRows:
-    """Spatially sorted copies of the two clouds of a dense launch + the block-sparse pattern "every slab of 256 rows x all
-    columns" (in a few column chunks, so that the column splits of the launch have something to split).  Both clouds are sorted
-    by voxel (``glhip_grid_cluster``) and the voxels chained along a boustrophedon path, so that every run of consecutive rows —
-    a 256-row slab, a 512-column tile — is spatially compact: the condition for the matrix-core distances (rows), and what lets
-    all but the few tiles around a slab skip the near-pair test (columns).  Slabs rather than one row block per voxel: voxels hold
-    244 +- 31 points where 256 were aimed at, and a workgroup per voxel left 18 % of the lanes idle (energy product at 1e6:
-    125 -> 105 ms; profiles/r03_dist_blocks.txt)."""
-
-    def __init__(self, xb, yb):
-        x, y = xb[0], yb[0]
-        N, M = x.shape[0], y.shape[0]
-        self.perm, xs = compact_order(x, _DIST_ROWS_PER_VOXEL)
-        self.perm_y, ys = compact_order(y, 2 * _DIST_ROWS_PER_VOXEL)
-        self.x, self.y = xs.unsqueeze(0).contiguous(), ys.unsqueeze(0).contiguous()
-        C = (N + _DIST_SLAB - 1) // _DIST_SLAB
-        first = torch.arange(C, device=x.device, dtype=torch.int32) * _DIST_SLAB
-        ranges = torch.stack((first, (first + _DIST_SLAB).clamp_max(N)), 1).contiguous()
-        nchunk = _DIST_COL_CHUNKS
-        step = ((M + nchunk - 1) // nchunk + 31) // 32 * 32
-        starts = torch.arange(nchunk, device=x.device, dtype=torch.int32) * step
-        cols = torch.stack((starts.clamp_max(M), (starts + step).clamp_max(M)), 1)      # (nchunk, 2)
-        red = cols.repeat(C, 1).contiguous()
-        slices = (torch.arange(1, C + 1, device=x.device, dtype=torch.int32) * nchunk).contiguous()
-        self.ranges = BlockRanges(ranges, slices, red, None, None, None)
-
-    def cols(self, t):
-        """A (1, M) per-column vector in the sorted column order."""
-        return None if t is None else t[:, self.perm_y].contiguous()
-
-    def rows(self, t):
-        return None if t is None else t[:, self.perm].contiguous()
-
-    def unsort(self, out_sorted):
-        """(1, N, ...) in sorted row order -> original order."""
-        out = torch.empty_like(out_sorted)
-        out[0, self.perm] = out_sorted[0]
-        return out
-
-
-def compact_rows_plan_applies(x, y, ranges=None, flags=0):
-    """Whether :func:`compact_rows_plan` would build a plan for these clouds (shapes and flags only: no device work)."""
+def autosort_applies(x, y, ranges=None, flags=0):
+    """Whether a dense distance-type launch (p = 1 soft-min / half-step, laplacian / energy product) over these clouds sorts them
+    inside the library (``csrc/glhip_autosort.h``: voxel sort along a boustrophedon path into the workspace, distances on the matrix
+    cores over slabs of 256 compact rows, results back in the caller's order).  Until round 5 this was a Python-side plan
+    (``_CompactRows``); it lives behind the C-ABI now, so a caller of ``glhip_softmin_fwd(p=1)`` gets it too.  Shapes and flags
+    only: no device work."""
     B = 1 if x.dim() == 2 else x.shape[0]
     N, M, D = x.shape[-2], y.shape[-2], x.shape[-1]
     flags = int(flags) | ENV_FLAGS
     return not (not _dist_on_mfma or ranges is not None or B != 1 or D > 3 or N < _DIST_MIN_ROWS or is_f64(x)
-                or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT)))
-
-
-def compact_rows_plan(x, y, ranges=None, flags=0):
-    """A :class:`_CompactRows` plan for the dense distance-type launches (p = 1 soft-min, laplacian / energy products) over the
-    clouds x (N,D)|(1,N,D), y likewise, or None when such launches are too small to be worth the two voxel sorts.
-
-    A plan holds voxel-sorted COPIES of the two clouds: it is valid as long as their contents do not change, which only the
-    caller knows (``x.data -= ...`` does not even bump ``x._version``).  So nothing is cached here: the loop that owns the clouds
-    builds the plan once and passes it down (``_HipSoftmin`` in sinkhorn_samples.py does, for the ~40 reductions of a Sinkhorn
-    loop); one-off calls of :func:`softmin` / :func:`kernel_conv` build their own — two sorts of ~1 ms against a reduction
-    of ~0.2 s at the sizes where plans apply."""
-    if is_f64(x):       # double-precision clouds run on glhip_*_f64, which take no plan
-        return None
-    xb = _points(x.detach(), "x")
-    yb = _points(y.detach(), "y")
-    xb, yb = (xb.unsqueeze(0) if xb.dim() == 2 else xb), (yb.unsqueeze(0) if yb.dim() == 2 else yb)
-    if yb.dtype != xb.dtype:
-        yb = yb.to(xb.dtype)
-    if not compact_rows_plan_applies(xb, yb, ranges, flags):
-        return None
-    return _CompactRows(xb, yb)
-
-
-def _plan_for(plan, xb, yb, ranges, flags):
-    """The caller's plan if it fits this launch, else a fresh one (or None)."""
-    if plan is not None:
-        if ranges is not None or plan.x.shape != xb.shape or plan.y.shape != yb.shape or plan.x.dtype != xb.dtype:
-            raise ValueError("geomloss_amd: the compact-rows plan was built for other clouds than the ones of this call.")
-        return plan
-    return compact_rows_plan(xb, yb, ranges, flags)
+                or float(N) * M < _DIST_MIN_PAIRS or (flags & (FLAG_NO_MFMA | FLAG_DIRECT | FLAG_NO_SORT)))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -760,17 +695,16 @@ class _Softmin(torch.autograd.Function):
     """f_i = -eps log sum_j exp(h_j - C(x_i,y_j)/eps); differentiable in x only, like the reference's call sites."""
 
     @staticmethod
-    def forward(ctx, x, y, h, eps, p, ranges, flags, plan=None):
+    def forward(ctx, x, y, h, eps, p, ranges, flags):
         xb, yb, hb, batched = _as_batched(_points(x, "x", True), _points(y, "y", True), h.detach().contiguous())
         if yb.dtype != xb.dtype:
             yb = yb.to(xb.dtype)
-        plan = _plan_for(plan, xb, yb, ranges, flags) if (p == 1 and not is_f64(xb)) else None
-        if plan is not None:       # large dense p = 1 launch: voxel-sorted clouds, squared distances on the matrix cores
-            out = plan.unsort(softmin_fwd_raw(plan.x, plan.y, plan.cols(hb), eps, p, plan.ranges, flags | FLAG_MFMA_DIST))
-        else:
-            if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+        if p == 1 and not is_f64(xb) and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+            if ranges is not None and _dist_on_mfma:
                 flags |= FLAG_MFMA_DIST            # multiscale: the row blocks are voxel clusters already
-            out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
+            elif not _dist_on_mfma:
+                flags |= FLAG_NO_SORT              # (big dense launches sort themselves inside the library unless told not to)
+        out = softmin_fwd_raw(xb, yb, hb, eps, p, ranges, flags)
         ctx.save_for_backward(x, yb, hb, out)         # (x itself: under create_graph the backward pass is differentiated through it)
         ctx.cfg = (eps, p, ranges, flags, xb.shape)
         return out if batched else out.view(-1)
@@ -785,7 +719,7 @@ class _Softmin(torch.autograd.Function):
         x, yb, hb, out = ctx.saved_tensors
         eps, p, ranges, flags, bshape = ctx.cfg
         gx = _bwd_x(x.reshape(bshape), grad_out.reshape(out.shape), yb, hb, out, eps, p, ranges, flags)
-        return gx.reshape(x.shape).to(x.dtype), None, None, None, None, None, None, None
+        return gx.reshape(x.shape).to(x.dtype), None, None, None, None, None, None
 
 
 class _SoftminValueGrad(torch.autograd.Function):
@@ -1013,10 +947,9 @@ def sinkhorn_last4(plan, x, y, eps, damping, pots):
 ENV_FLAGS = int(os.environ.get("GEOMLOSS_HIP_FLAGS", "0"))
 
 
-def softmin(eps, x, y, h, p=2, ranges=None, flags=0, plan=None):
-    """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32.
-    ``plan``: a :func:`compact_rows_plan` of (x, y) that the caller keeps across calls (p = 1, large dense launches)."""
-    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS, plan)
+def softmin(eps, x, y, h, p=2, ranges=None, flags=0):
+    """Soft-C-transform on the GPU.  x: (N,D)|(B,N,D), y: (M,D)|(B,M,D), h: (M,)|(B,M) -> (N,)|(B,N) fp32."""
+    return _Softmin.apply(x, y, h, float(eps), int(p), ranges, int(flags) | ENV_FLAGS)
 
 
 def fused_step_applies(D, p=2, flags=0, sparse=False):
@@ -1031,7 +964,7 @@ def fused_step_applies(D, p=2, flags=0, sparse=False):
     return p == 2 or (p == 1 and not sparse)
 
 
-def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0, plan=None):
+def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0):
     """One non-differentiable half-step of the Sinkhorn loop on the GPU: (prev + damping * softmin(eps, C, logw + pot/eps)) / 2,
     or damping * softmin(...) when prev is None — ONE launch where :func:`fused_step_applies`, the soft-min kernel followed by
     torch arithmetic elsewhere (D > 16, block-sparse p = 1 in D > 3, D > 3 under GLHIP_FLAG_NO_MFMA / GLHIP_FLAG_DIRECT).
@@ -1041,7 +974,7 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     if not fused_step_applies(x.shape[-1], p, flags, ranges is not None) or is_f64(x):      # (float64 clouds: the double-precision kernels have no fused form)
         with torch.no_grad():
             h = _vec(logw, x) if pot is None else _vec(logw, x) + _vec(pot, x).reshape(logw.shape) / eps
-            ft = damping * softmin(eps, x.detach(), y.detach(), h, p=p, ranges=ranges, flags=flags, plan=plan)
+            ft = damping * softmin(eps, x.detach(), y.detach(), h, p=p, ranges=ranges, flags=flags)
             return ft if prev is None else 0.5 * (_vec(prev, x).reshape(ft.shape) + ft)
     xb, yb, lw, batched = _as_batched(_points(x.detach(), "x"), _points(y.detach(), "y"), _f32(logw))
     if yb.dtype != xb.dtype:
@@ -1050,14 +983,12 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
     pt = None if pot is None else _f32(pot).reshape(B, -1)
     pv = None if prev is None else _f32(prev).reshape(B, -1)
     flags = int(flags) | ENV_FLAGS
-    plan = _plan_for(plan, xb, yb, ranges, flags) if p == 1 else None
-    if plan is not None:           # large dense p = 1 launch: voxel-sorted clouds (the loop passes its plan: built once per loss)
-        out = plan.unsort(sinkhorn_step_raw(plan.x, plan.y, plan.cols(lw), plan.cols(pt), plan.rows(pv), eps, damping, p, plan.ranges,
-                                            flags | FLAG_MFMA_DIST))
-    else:
-        if p == 1 and ranges is not None and _dist_on_mfma and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+    if p == 1 and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+        if ranges is not None and _dist_on_mfma:
             flags |= FLAG_MFMA_DIST
-        out = sinkhorn_step_raw(xb, yb, lw, pt, pv, eps, damping, p, ranges, flags)
+        elif not _dist_on_mfma:
+            flags |= FLAG_NO_SORT
+    out = sinkhorn_step_raw(xb, yb, lw, pt, pv, eps, damping, p, ranges, flags)
     return out if batched else out.view(-1)
 
 
@@ -1114,30 +1045,25 @@ class _KernelConv(torch.autograd.Function):
         fused = (_fuse_kernel_grad and want_unit
                  and (xb.shape[-1] <= 3 or (kind == GAUSSIAN and xb.shape[-1] <= XD_MAX_DIM and not (flags & FLAG_NO_MFMA))))
         # laplacian / energy: squared distances from the matrix cores wherever the row blocks are spatially compact — the voxel
-        # clusters of the multiscale backend as they are, large dense launches after a voxel sort of both clouds (plan) — for the
-        # product, the product + gradient and (GRAD_FAMILY) the companion products of a norm alike
-        plan, fl = None, flags
-        if kind != GAUSSIAN and _dist_on_mfma and xb.shape[-1] <= 3 and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
-            if ranges is not None:
+        # clusters of the multiscale backend as they are, large dense launches after the voxel sort the library does itself
+        # (csrc/glhip_autosort.h) — for the product, the product + gradient and (GRAD_FAMILY) the companion products of a norm alike
+        fl = flags
+        if kind != GAUSSIAN and xb.shape[-1] <= 3 and not (flags & (FLAG_NO_MFMA | FLAG_DIRECT)):
+            if ranges is not None and _dist_on_mfma:
                 fl |= FLAG_MFMA_DIST
-            else:
-                plan = compact_rows_plan(xb, yb, ranges, flags)
+            elif not _dist_on_mfma:
+                fl |= FLAG_NO_SORT
         rows = None
-        if plan is not None:
-            X, Y, V, R, fl = plan.x, plan.y, plan.cols(vb), plan.ranges, fl | FLAG_MFMA_DIST
-        else:
-            X, Y, V, R = xb, yb, vb, ranges
-            if fused or (flags & FLAG_GRAD_FAMILY):      # gaussian: the kernels with one centre per workgroup
-                rows = _gauss_compact_rows(kind, xb, yb.shape[1], ranges, flags)
-                if rows is not None:
-                    X = rows[1]
+        X, Y, V, R = xb, yb, vb, ranges
+        if fused or (flags & FLAG_GRAD_FAMILY):      # gaussian: the kernels with one centre per workgroup
+            rows = _gauss_compact_rows(kind, xb, yb.shape[1], ranges, flags)
+            if rows is not None:
+                X = rows[1]
         if fused:
             out, unit = kernel_conv_fwd_grad_raw(kind, X, Y, V, blur, R, fl)
         else:
             out, unit = kernel_conv_fwd_raw(kind, X, Y, V, blur, R, fl), None
-        if plan is not None:
-            out, unit = plan.unsort(out), (None if unit is None else plan.unsort(unit))
-        elif rows is not None:
+        if rows is not None:
             out, unit = _unsort_rows(rows[0], out), (None if unit is None else _unsort_rows(rows[0], unit))
         return xb, yb, vb, batched, out, unit
 

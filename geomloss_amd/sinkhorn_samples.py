@@ -104,10 +104,10 @@ def _fp32_weights(a, b):
     return a, b
 
 
-def softmin_online(eps, C_xy, h_y, p=2, plan=None, flags=0):
+def softmin_online(eps, C_xy, h_y, p=2, flags=0):
     """Soft-C-transform on implicit costs (``:337-346`` and ``:229-290``): C_xy = (x, y), batched or not."""
     x, y = C_xy
-    out = hip.softmin(eps, x, y, h_y, p=p, plan=plan, flags=flags)
+    out = hip.softmin(eps, x, y, h_y, p=p, flags=flags)
     return out if x.dim() > 2 else out.view(1, -1)
 
 
@@ -119,19 +119,6 @@ class _HipSoftmin:
         self.p, self.multiscale = p, multiscale
         self.h2_min_eps = float("inf")      # see set_range: temperatures from which the f16 x 2 exponent layout is in range
         self._plan = None   # (x, y, a_log, b_log, debias, hip.Iter4Plan) of the loop being run
-        self._dist_plans = {}   # p = 1, dense: (id(x), id(y)) -> (x, y, hip.compact_rows_plan): voxel-sorted copies, per loop
-
-    def _dist_plan(self, x, y):
-        """The voxel-sorted copies of (x, y) behind the matrix-core distance kernel, built once for the ~10 reductions the loop
-        runs over this pair of clouds.  This object lives for one loss evaluation and holds the tensors it keys on, so a plan can
-        neither outlive its clouds nor see them change (the loop never writes to them)."""
-        if self.p != 1 or self.multiscale or x.dim() != 2:
-            return None
-        key = (id(x), id(y))
-        hit = self._dist_plans.get(key)
-        if hit is None:
-            hit = self._dist_plans[key] = (x, y, hip.compact_rows_plan(x, y))
-        return hit[2]
 
     def set_range(self, extent):
         """Tells the soft-min how wide the clouds ARE (the diagonal of their bounding box, or an upper bound of it; None: unknown),
@@ -155,7 +142,7 @@ class _HipSoftmin:
     def __call__(self, eps, C, h):
         if self.multiscale:
             return softmin_multiscale(eps, C, h, p=self.p, flags=self._flags(eps))
-        return softmin_online(eps, C, h, p=self.p, plan=self._dist_plan(C[0], C[1]), flags=self._flags(eps))
+        return softmin_online(eps, C, h, p=self.p, flags=self._flags(eps))
 
     def step(self, eps, C, log_w, pot, damping, prev):
         x, y = C[0], C[1]
@@ -164,8 +151,7 @@ class _HipSoftmin:
             ft = damping * self(eps, C, log_w if pot is None else log_w + pot / eps)
             return ft if prev is None else 0.5 * (prev + ft)
         flat = (lambda t: None if t is None else t.reshape(-1)) if x.dim() == 2 else (lambda t: t)
-        out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges,
-                                plan=self._dist_plan(x, y), flags=self._flags(eps))
+        out = hip.sinkhorn_step(eps, x, y, flat(log_w), flat(pot), flat(prev), damping, p=self.p, ranges=ranges, flags=self._flags(eps))
         return out.view(1, -1) if (x.dim() == 2 and not self.multiscale) else out
 
     def value_and_grad(self, eps, C, log_w, pot_new, pot_old, f_new, f_old, damping):
@@ -193,7 +179,7 @@ class _HipSoftmin:
         x, y = C_xy[0], C_xy[1]
         if self.p not in (1, 2) or x.shape[-1] > hip.XD_MAX_DIM or not _fuse_iterations or x.dtype == torch.float64:
             return None
-        if self.p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x)):
+        if self.p == 1 and (hip.autosort_applies(x, y) or hip.autosort_applies(y, x)):
             return None     # big p = 1 clouds: one voxel-sorted launch per soft-min (glhip_dist_x32.h) beats the fused iteration
         if hip.ENV_FLAGS & (hip.FLAG_NO_MFMA | hip.FLAG_DIRECT | hip.FLAG_F32_MFMA | hip.FLAG_XDL16):
             return None     # the one-launch iteration exists on the default kernel only: a kernel-selection flag means "not that one"
@@ -324,7 +310,7 @@ def sinkhorn_online(
     a_log, b_log = log_weights_many([a, b])
     # (p = 1 on clouds big enough for the voxel-sorted distance plans: those are built with a host read-back, which a stream
     # capture does not allow — and launches of that size gain nothing from a graph)
-    sorts = p == 1 and (hip.compact_rows_plan_applies(x, y) or hip.compact_rows_plan_applies(y, x))
+    sorts = p == 1 and (hip.autosort_applies(x, y) or hip.autosort_applies(y, x))
     if _graph_mode and diameter_given and x.is_cuda and x.shape[-1] <= 3 and not sorts and x.dtype != torch.float64:
         f_aa, g_bb, g_ab, f_ba = _graphed_loop(softmin, x, y, a_log, b_log, eps_list, rho, debias)
     else:

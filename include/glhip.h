@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 114 /* 0.1.14 */
+#define GLHIP_VERSION 115 /* 0.1.15 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -84,6 +84,13 @@ extern "C" {
                                   exponent term (log2(e) h_j, |x - y|^2 / (2 eps ln 2)) must stay below ~2.6e5 in magnitude, i.e. roughly
                                   (cloud diameter)^2 / eps < 3e5; beyond that f16 overflows and the results are inf / nan.  Ignored by kernels
                                   without that layout (p = 1, laplacian, energy, D > 16, float64). */
+
+#define GLHIP_FLAG_NO_SORT 512 /* p = 1 soft-min / half-step, laplacian and energy products: big dense launches (B = 1, D <= 3, N >= 65536,
+                                  N M >= 5e8, a workspace of glhip_workspace_bytes) sort both clouds into the workspace themselves — voxel sort along a
+                                  boustrophedon path, csrc/glhip_autosort.h — so that the squared distances can come from the matrix cores
+                                  (GLHIP_FLAG_MFMA_DIST on slabs of 256 compact rows): 346 -> ~200 ms at N = M = 1e6.  Results come back in the
+                                  caller's order; values differ from the unsorted launch by rounding only.  This flag keeps the clouds as they
+                                  are (the generic explicit-difference kernel), e.g. for callers that hand in sorted clouds and their own ranges. */
 
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
  *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic

@@ -161,6 +161,50 @@ int main(void) {
     oracle_softmin(xd, yd, hd, ref, N, M, D, (double)eps, 2, NULL, NULL, NULL, 0);
     report("glhip_softmin_fwd without workspace", max_abs(out_h, ref, N, 0), 3e-6);
 
+    /* 5b. big dense DISTANCE reductions sort their clouds behind the ABI (glhip_autosort.h; N >= 65536, N M >= 5e8): p = 1 soft-min,
+     *     laplacian and energy products at 70 000 x 66 000 — against the oracle on a sample of rows, and against the same call
+     *     under GLHIP_FLAG_NO_SORT (the generic kernel on the caller's order): one answer, two kernels */
+    {
+        enum { NB = 70000, MB = 66000, NS = 96 };
+        float* xb = malloc(sizeof(float) * NB * D), *yb = malloc(sizeof(float) * MB * D), *hb = malloc(sizeof(float) * MB), *vb = malloc(sizeof(float) * MB);
+        float *o1 = malloc(sizeof(float) * NB), *o2 = malloc(sizeof(float) * NB);
+        double *yq = malloc(sizeof(double) * MB * D), *hq = malloc(sizeof(double) * MB), *vq = malloc(sizeof(double) * MB);
+        for (int k = 0; k < NB * D; ++k) xb[k] = (float)uniform();
+        for (int k = 0; k < MB * D; ++k) yq[k] = yb[k] = (float)(0.1 + 0.8 * uniform());
+        for (int k = 0; k < MB; ++k) { hq[k] = hb[k] = (float)(0.3 * normal() - log((double)MB)); vq[k] = vb[k] = (float)(uniform() / MB); }
+        void *X = to_device(xb, sizeof(float) * NB * D), *Y = to_device(yb, sizeof(float) * MB * D);
+        float *H = to_device(hb, sizeof(float) * MB), *V = to_device(vb, sizeof(float) * MB), *O = to_device(NULL, sizeof(float) * NB);
+        const size_t wb = glhip_workspace_bytes(1, NB, MB, D, 0);
+        void* W = to_device(NULL, wb);
+        static double xs[NS * D], rs[NS];
+        static float got[NS];
+        for (int mode = 0; mode < 3; ++mode) {        /* 0: soft-min p = 1, 1: laplacian, 2: energy */
+            for (int pass = 0; pass < 2; ++pass) {
+                const int fl = pass ? GLHIP_FLAG_NO_SORT : 0;
+                if (mode == 0) GL_OK(glhip_softmin_fwd(X, Y, H, O, 1, NB, MB, D, 0.05f, 1, GLHIP_F32, NULL, NULL, NULL, 0, W, wb, fl, stream));
+                else GL_OK(glhip_kernel_conv_fwd(mode == 1 ? GLHIP_LAPLACIAN : GLHIP_ENERGY, X, Y, V, O, 1, NB, MB, D, 0.1f, GLHIP_F32, NULL, NULL, NULL, 0, W, wb, fl, stream));
+                HIP_OK(hipStreamSynchronize(stream));
+                HIP_OK(hipMemcpy(pass ? o2 : o1, O, sizeof(float) * NB, hipMemcpyDeviceToHost));
+            }
+            double between = 0.0, scale = 0.0;
+            for (int i = 0; i < NB; ++i) { between = fmax(between, fabs((double)o1[i] - o2[i])); scale = fmax(scale, fabs((double)o2[i])); }
+            for (int k = 0; k < NS; ++k) {
+                const int i = (int)((long)k * (NB - 1) / (NS - 1));
+                for (int d = 0; d < D; ++d) xs[k * D + d] = xb[i * D + d];
+                got[k] = o1[i];
+            }
+            if (mode == 0) oracle_softmin(xs, yq, hq, rs, NS, MB, D, 0.05, 1, NULL, NULL, NULL, 0);
+            else oracle_kconv(mode == 1 ? GLHIP_LAPLACIAN : GLHIP_ENERGY, xs, yq, vq, rs, NS, MB, D, 0.1, NULL, NULL, NULL, 0);
+            char name[96];
+            snprintf(name, sizeof name, "self-sorting dense launch, mode %d: sampled rows vs oracle (relative)", mode);
+            report(name, max_abs(got, rs, NS, 1), 2e-5);
+            snprintf(name, sizeof name, "   ... vs the same call under GLHIP_FLAG_NO_SORT (relative)");
+            report(name, between / scale, 2e-5);
+        }
+        HIP_OK(hipFree(X)); HIP_OK(hipFree(Y)); HIP_OK(hipFree(H)); HIP_OK(hipFree(V)); HIP_OK(hipFree(O)); HIP_OK(hipFree(W));
+        free(xb); free(yb); free(hb); free(vb); free(o1); free(o2); free(yq); free(hq); free(vq);
+    }
+
     /* 6. error paths: code + thread-local message, nothing thrown across the ABI */
     {
         int rc = glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 3, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream);
