@@ -575,7 +575,7 @@ def sinkhorn_multiscale(
         # The coarse level of a big problem runs in float64.  Two samples of one law at N = 1e6 leave a gradient of 1e-3 of a blur and a
         # loss of 1e-4 of its terms, and the float32 rounding of the coarse trajectory (potentials of size 1 at the first temperatures:
         # 1e-7 per cluster and iteration) reaches them through the nearly undamped mode (f + c(x), g - c(y)): dL/dx was 4e-5 .. 6e-5 of
-        # its max-norm from the float64 oracle (profiles/r06_full_size_parity.txt).  ~2000 clusters: 36 float64 soft-mins of 35 us
+        # its max-norm away from a float64 run (profiles/r06_full_size_parity.txt).  ~2000 clusters: 36 float64 soft-mins of 35 us
         # (glhip_api_f64.hip spreads their rows over wavefronts) plus their torch arithmetic, < 1 % of such a loss.
         a_c, b_c, x_c, y_c = a_c.double(), b_c.double(), x_c.double(), y_c.double()
     la_c, la, lb_c, lb = log_weights_many([a_c, a, b_c, b])
