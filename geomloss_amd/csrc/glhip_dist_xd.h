@@ -3,7 +3,7 @@
 //
 // The reference evaluates them with one KeOps formula whatever D is (`"Norm2(X-Y)"`, _legacy/sinkhorn_samples.py:316-319;
 // `kernel_samples.py:71-82`).  Until round 4 everything beyond D = 3 went to the one-thread-per-row VALU kernel of glhip_generic.h:
-// 2 D + 6 instructions per pair, 0.8e12 pairs/s at D = 4 ... 8 and 0.4e12 at D = 16 (tools/scratch measurement of round 5), a fifth
+// 2 D + 6 instructions per pair, 0.8e12 pairs/s at D = 4 ... 8 and 0.4e12 at D = 16 (measured in round 5), a fifth
 // of the D <= 3 kernels.  Here the scaled squared distance of a 32 x 32 block of pairs is the chain of MFMAs of glhip_softmin_xd.h,
 //     d2_ij = |xs_i|^2 + |ys_j|^2 - 2 xs_i . ys_j,      xs = t (x - c), ys = t (y - c),
 // with the K layout of that header (bf16 x 3: a squared distance is a difference of large terms and needs all 24 bits):

@@ -189,7 +189,7 @@ class SamplesLoss(Module):
     def generate_weights(self, x):
         # Uniform weights 1/N (``samples_loss.py:325-335``), created on the device of x: the reference builds them on the CPU
         # and copies (`torch.ones(N).type_as(x)`), a pageable host-to-device copy that stalls the HIP queue for ~90 ms every
-        # few calls (measured: a 3.5-ms batched loss spiking to 90-190 ms, tools/probe_spikes2.py).
+        # few calls (measured: a 3.5-ms batched loss spiking to 90-190 ms, round 3, HISTORY.md).
         # One fill launch: the value is `1 / N` rounded as that division rounds it in the dtype of x (_uniform_weight).
         if x.dim() == 2:
             N = x.shape[0]

@@ -401,7 +401,7 @@ def clusterize(a, x, scale=None, labels=None):
 # GEOMLOSS_HIP_DENSE_SWITCH=0 keeps the pattern everywhere (A/B, tests).
 _DENSE_SWITCH = os.environ.get("GEOMLOSS_HIP_DENSE_SWITCH", "1")
 _DENSE_SWITCH_MIN_EXPONENT = 16.0
-_DENSE_SWITCH_RATE = 0.45         # pairs per second of a block-sparse launch with full tiles, as a share of the dense kernel's (fitted: tools/probe_dense_switch.py)
+_DENSE_SWITCH_RATE = 0.45         # pairs per second of a block-sparse launch with full tiles, as a share of the dense kernel's (fitted: profiles/r04_dense_switch.txt)
 
 
 def set_dense_switch(mode):

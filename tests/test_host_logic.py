@@ -597,7 +597,7 @@ def test_dense_switch_cost_model_and_exponent_gate():
     """sinkhorn_samples.dense_is_cheaper / _goes_dense: the fine level of a two-scale loss stays dense when the pattern keeps most of
     the matrix or its clusters fill a fraction of the 32-row tiles — and only where the dropped pairs cannot matter."""
     import geomloss_amd.sinkhorn_samples as ss
-    # measured on an MI355X (tools/probe_dense_switch.py): D = 3 keeps 21 % at every N; dense wins up to 3e4 points, the pattern from 1e5
+    # measured on an MI355X (profiles/r04_dense_switch.txt): D = 3 keeps 21 % at every N; dense wins up to 3e4 points, the pattern from 1e5
     assert ss.dense_is_cheaper(0.21 * 1e4 ** 2, 10_000, 10_000, 2000, 2000)
     assert ss.dense_is_cheaper(0.21 * 3e4 ** 2, 30_000, 30_000, 2140, 2140)
     assert not ss.dense_is_cheaper(0.21 * 1e5 ** 2, 100_000, 100_000, 2170, 2170)

@@ -40,9 +40,10 @@ leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_rep
 leg fuzz gpurun_out/fuzz.txt 200 python tools/fuzz_kernels.py 600 3
 leg fuzz_highd gpurun_out/fuzz_highd.txt 200 python tools/fuzz_highd.py 300 3
 leg small_probe gpurun_out/small_probe.txt 200 python tools/small_probe.py
-leg probe_shards gpurun_out/probe_shards.txt 200 python tools/probe_shards.py --calls 200
-leg probe_f16x2 gpurun_out/probe_f16x2.txt 400 python tools/probe_f16x2.py --dims 3,4,8,12,16
-leg probe_dist_xd gpurun_out/probe_dist_xd.txt 300 python tools/probe_dist_xd.py
+leg multiscale_pmc gpurun_out/multiscale_pmc.txt 600 env MIN_NS=5e6 PAIRS=2.1e11 bash tools/profile_kernels.sh ${TAG}_ms multiscale_1e6.py   # the block-sparse kernels of config 3
+leg raw_p1 gpurun_out/raw_p1_1e6.txt 200 python tools/raw_p1_1e6.py             # the self-sorting distance reductions through the raw C-ABI
+leg bench_f64 gpurun_out/bench_f64.txt 200 python tools/bench_f64.py
+leg sparse_ideal gpurun_out/sparse_ideal.txt 200 python tools/probe_sparse_ideal.py
 leg first_call gpurun_out/first_call.txt 100 python tools/first_call.py
 leg reference_protocol gpurun_out/reference_protocol.log 500 python tools/reference_protocol_bench.py --quick
 cat $STATUS
