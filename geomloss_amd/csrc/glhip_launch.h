@@ -117,8 +117,8 @@ enum { FWD_F32 = 0, FWD_XDL16 = 1, FWD_X32 = 2 };
 
 template <int D, typename T, int KIND, int NW, bool SPARSE, int L = XL_BF16X3>
 void launch_fwd_kernel(dim3 grid, hipStream_t st, const SoftminParams<T>& prm, const Ranges& rg, int N, int M, const SplitInfo& sp) {
-    if (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false, L>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
-    else if (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
+    if constexpr (KIND == FWD_X32) hipLaunchKernelGGL((softmin_fwd_x32_kernel<D, T, SPARSE, 1, NW, false, L>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp, PackedCols{nullptr, 0});
+    else if constexpr (KIND == FWD_XDL16) hipLaunchKernelGGL((softmin_fwd_xdl_kernel<D, T, SPARSE, kFwdRT, NW>), grid, dim3(NW * 64), 0, st, prm, rg, N, M, sp);
     else hipLaunchKernelGGL((softmin_fwd_mfma_kernel<D, T, SPARSE, kFwdRT>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
 
@@ -236,7 +236,7 @@ void launch_softmin_mfma(const SoftminParams<T>& prm, const Ranges& rg, int n_ra
             return;
         }
     }
-    if (KIND == FWD_F32)
+    if constexpr (KIND == FWD_F32)
         launch_softmin_mfma_nw<D, T, FWD_F32, 4>(prm, rg, n_ranges, B, N, M, sc, st);
     else if (KIND == FWD_X32 && n_ranges > 0 && sc.small_rows && !forced_nw)
         // the caller says the pairs sit in row blocks of up to 64 points (GLHIP_FLAG_SMALL_ROW_BLOCKS): 2 wavefronts x 256-column
@@ -434,7 +434,7 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
         // pre-packed columns (glhip_softmin_xd.h): the records of all columns once, in workspace behind the split partials
         XdPacked pk{nullptr, (long)((M + 31) / 32) * S::kGroupRecs};
         const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
-        static const bool allow_pre = []() { const char* e = getenv("GLHIP_XD_PRE"); return !e || atoi(e) != 0; }();   // A/B knob
+        constexpr bool allow_pre = true;      // (A/B knob GLHIP_XD_PRE of rounds 4-5: pre-packed columns won, the knob is gone)
         const long fit_pre = (sc.ws && sc.bytes > packed_bytes + 256) ? (long)((sc.bytes - packed_bytes - 256) / per_split) : 0;
         const bool pre = NW == 8 && allow_pre && sc.prepack((double)B * N * M) && fit_pre >= 8;
         const int nx = pre ? xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0) : xcd_splits((long)gx * B, M, kXdSlots, fit);
@@ -500,10 +500,10 @@ void launch_xd(const SoftminParams<T>& prm, const typename MergeOp::Params& mprm
 
 // distance reductions for 4 <= D <= 16, dense launches (glhip_dist_xd.h): soft-min p = 1 / fused half-step, laplacian and energy products
 // 256-row workgroups of the distance kernels on a few thousand points are a handful (N = 1000: 4 per problem): launches with fewer than
-// 512 workgroups split their columns down to GLHIP_DIST_MULTI_MIN_COLS (128) per split, up to 32 splits and what the workspace holds
+// 512 workgroups split their columns down to 128 per split, up to 32 splits and what the workspace holds
 // (online p = 1 losses at N = 1000 / 2000: 0.53 / 0.49 -> 0.35 / 0.38 ms)
 static inline int dist_small_launch_splits(int n_splits, long row_blocks, int M, long fit, bool allow_split) {
-    static const int min_cols = getenv("GLHIP_DIST_MULTI_MIN_COLS") ? atoi(getenv("GLHIP_DIST_MULTI_MIN_COLS")) : 128;
+    constexpr int min_cols = 128;
     if (!allow_split || min_cols <= 0 || row_blocks * n_splits >= 512) return n_splits;
     long want = (512 + row_blocks - 1) / row_blocks;
     const long by_cols = M / min_cols;
@@ -609,7 +609,7 @@ void launch_wsum_t32(const WsumParams<T>& prm, const typename MergeOp::Params& m
     // 2 row tiles per wavefront share the LDS reads of a column group (4 wavefronts x 64 rows) up to D = 8 — measured 3-16 % faster
     // than 1 tile there (profiles/r03_grad_kernels_ab.txt); beyond, the x-side operands of two tiles no longer fit 128 VGPRs
     if constexpr (MODE == WS_SOFTMIN_BWD) {
-        static const int wq_min_d = getenv("GLHIP_WQ_MIN_D") ? atoi(getenv("GLHIP_WQ_MIN_D")) : 7;      // tuning knob (17: never)
+        constexpr int wq_min_d = 7;      // (measured in round 5: the matrix-core weighted sums pay from D = 7 on)
         if (sc.h2 && D >= wq_min_d) {
             launch_wsum_t32_rt<MODE, D, T, MergeOp, 1, XL_F16X2, true>(prm, mprm, rg, n_ranges, B, N, M, sc, st);
             return;
@@ -661,9 +661,15 @@ void launch_softmin_d(const SoftminParams<T>& prm, const Ranges& rg, int n_range
     if constexpr (BWD) {
         launch_softmin_bwd_mfma<D, T>(prm, rg, n_ranges, B, N, M, sc, kind == FWD_X32, st);
     } else {   // `if constexpr`: the gradient translation unit does not instantiate the forward kernels, and vice versa
-        if (kind == FWD_X32) launch_softmin_mfma<D, T, FWD_X32>(prm, rg, n_ranges, B, N, M, sc, st);
-        else if (kind == FWD_XDL16) launch_softmin_mfma<D, T, FWD_XDL16>(prm, rg, n_ranges, B, N, M, sc, st);
-        else launch_softmin_mfma<D, T, FWD_F32>(prm, rg, n_ranges, B, N, M, sc, st);
+        // The two earlier tilings of the soft-min forward — fp32 MFMA (GLHIP_FLAG_F32_MFMA) and bf16 x 3 on 16x16x32 MFMAs
+        // (GLHIP_FLAG_XDL16) — only ever served A/B runs against the shipped 32x32x16 kernel: they are compiled in with
+        // `make AB=1` (-DGLHIP_AB_KERNELS) and left out of the shipped library, where the two flags select the default kernel.
+#ifdef GLHIP_AB_KERNELS
+        if (kind == FWD_XDL16) { launch_softmin_mfma<D, T, FWD_XDL16>(prm, rg, n_ranges, B, N, M, sc, st); return; }
+        if (kind == FWD_F32) { launch_softmin_mfma<D, T, FWD_F32>(prm, rg, n_ranges, B, N, M, sc, st); return; }
+#endif
+        (void)kind;
+        launch_softmin_mfma<D, T, FWD_X32>(prm, rg, n_ranges, B, N, M, sc, st);
     }
 }
 
@@ -694,9 +700,9 @@ SoftminParams<T> make_softmin_params(const void* x, const void* y, const float* 
 }
 
 // glhip_sinkhorn_iter4: `count` dense p = 2 reductions in one launch of the x32 forward kernel + one merge launch
-// rows x columns of one problem up to which an unbatched multi launch runs without column splits (GLHIP_TINY_MULTI_PAIRS: tuning knob)
+// rows x columns of one problem up to which an unbatched multi launch runs without column splits (5e6, measured)
 static inline double tiny_multi_pairs() {
-    static const double v = getenv("GLHIP_TINY_MULTI_PAIRS") ? atof(getenv("GLHIP_TINY_MULTI_PAIRS")) : 5e6;
+    constexpr double v = 5e6;
     return v;
 }
 
@@ -729,8 +735,6 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
     // ... and none on tiny unbatched problems: the launch takes as long either way (N = M = 2000: 17.8 us with 3 splits + merge, 18.1 us
     // with one), and a loop of such launches is bound by the host's launch rate — the merge kernel is one launch in three
     if (B == 1 && (double)maxN * maxM_all(m) <= tiny_multi_pairs()) sp.n_splits = 1;
-    static const int force_splits = getenv("GLHIP_ITER4_SPLITS") ? atoi(getenv("GLHIP_ITER4_SPLITS")) : 0;   // tuning knob
-    if (force_splits > 0 && sc.allow_split && fit >= force_splits && minM / force_splits >= 64) sp.n_splits = force_splits;
     sp.workspace = static_cast<float*>(sc.ws);
     sp.split_stride = 0;   // per problem, set in the kernels
     sp.xcd_grid_x = 0;
@@ -748,7 +752,7 @@ void launch_iter4(SoftminMulti<T>& m, int B, const Scratch& sc, hipStream_t st) 
         maxM = m.M[k] > maxM ? m.M[k] : maxM;
         m.pk[k] = PackedCols{nullptr, (long)((m.M[k] + 31) / 32) * (32 * NR)};
     }
-    static const double pre_min = getenv("GLHIP_ITER4_PRE_MIN") ? atof(getenv("GLHIP_ITER4_PRE_MIN")) : 1e8;   // tuning knob
+    constexpr double pre_min = 1e8;
     bool pre = sc.ws && sc.allow_split && pairs >= pre_min;
     if (pre) {
         size_t off = (((size_t)(sp.n_splits > 1 ? m.count : 0) * (size_t)m.ws_stride * sizeof(float)) + 255) & ~(size_t)255;
@@ -966,7 +970,7 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
             // Big dense launches only (pre-packed columns, XCD-aware grid): that is where it was measured to win — 87.1 -> 79.2 ms at
             // 1e6 x 1e6, 36.8 -> 35.0 ms per online loss at 1e5; batches of 4096 x 4096 problems lose 4 % to the x32 kernel's staging
             // (B = 256: 16.2 -> 17.0 ms per loss), and block-sparse launches keep the gathered pre-packed tiles of glhip_softmin_x32.h.
-            static const bool via_xd = getenv("GLHIP_H2_VIA_XD") ? atoi(getenv("GLHIP_H2_VIA_XD")) != 0 : true;      // A/B knob
+            constexpr bool via_xd = true;
             // (block-sparse launches through this kernel, packing their tiles on the fly in 512-row workgroups: 281 vs 244 ms per two-scale
             // loss at 1e6, round 6)
             if (via_xd && p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {

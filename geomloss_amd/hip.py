@@ -748,7 +748,7 @@ class _SoftminValueGrad(torch.autograd.Function):
         return gx.reshape(xshape).to(xdtype), None, None, None, None, None, None, None
 
 
-_VALUE_GRAD_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_VALUE_GRAD_MIN_PAIRS", "5e8"))
+_VALUE_GRAD_MIN_PAIRS = 5e8
 _VALUE_GRAD_MAX_MARGIN = 25.0       # in units of eps: the weights stay >= exp(-50) of the largest one
 
 
@@ -998,7 +998,7 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
 # common bias of -1.6e-5 on every term of a norm at blur = .05 in the unit cube when the rows of a workgroup are scattered over
 # the cloud.  With the rows in compact order (256 neighbours per workgroup) |x - c| is the size of a voxel and the bias drops to
 # -1.2e-6 (profiles/r03_upper_triangle.txt).  Large dense launches only: the sort costs ~1 ms at 1e6 points.
-_GAUSS_SORT_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_GAUSS_SORT_MIN", "1e11"))
+_GAUSS_SORT_MIN_PAIRS = 1e11
 
 
 def _gauss_compact_rows(kind, xb, M, ranges, flags):
@@ -1135,8 +1135,8 @@ class _KernelConv(torch.autograd.Function):
         return _unsort_rows(perm, kernel_conv_bwd_x_raw(kind, X, cols_pts, v, g[:, perm].contiguous(), blur, ranges, flags))
 
 
-# product + row gradient in one pass when x requires gradients (GEOMLOSS_HIP_FUSE_GRAD=0: always two reductions)
-_fuse_kernel_grad = os.environ.get("GEOMLOSS_HIP_FUSE_GRAD", "1") != "0"
+# product + row gradient in one pass when x requires gradients (set_kernel_grad_fusion(False): always two reductions)
+_fuse_kernel_grad = True
 
 
 def set_kernel_grad_fusion(enabled):

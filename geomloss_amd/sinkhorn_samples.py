@@ -205,7 +205,7 @@ class _HipSoftmin:
 
     def anneal(self, eps_list, dampings, C_xy, a_log, b_log, debias):
         """The initialisation and all the iterations of a level queued by one library call (``glhip_sinkhorn_anneal``), or None where
-        :meth:`iter4` does not apply (see _iter4_plan) or GEOMLOSS_HIP_ANNEAL=0.  Returns (final potentials, inputs of the last
+        :meth:`iter4` does not apply (see _iter4_plan) or `_anneal_in_library` is off.  Returns (final potentials, inputs of the last
         iteration).  Same launches as one :meth:`iter4` call per temperature — the f16 x 2 layout from the same temperature on —
         without the Python interpreter between them: what bounds a loop on a few thousand points."""
         if not _anneal_in_library:
@@ -243,10 +243,10 @@ class _HipSoftmin:
 _graph_mode = os.environ.get("GEOMLOSS_HIP_GRAPH", "0") == "1"
 _COARSE_F64_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_COARSE_F64_MIN_PAIRS", "1e11"))   # two-scale losses: float64 coarse level from here on
 _F16X2 = os.environ.get("GEOMLOSS_HIP_F16X2", "1") != "0"      # f16 x 2 exponents where the temperature allows (_HipSoftmin.set_range)
-_anneal_in_library = os.environ.get("GEOMLOSS_HIP_ANNEAL", "1") != "0"   # the iterations of a level queued by one library call (A/B knob)
-_fuse_iterations = os.environ.get("GEOMLOSS_HIP_ITER4", "1") != "0"   # one launch per Sinkhorn iteration (small / mid-size clouds)
+_anneal_in_library = True   # the iterations of a level queued by one library call (tests switch it off to compare with one call per iteration)
+_fuse_iterations = True   # one launch per Sinkhorn iteration (small / mid-size clouds); set_iteration_fusion(False): four half-steps
 # ... up to this many pairs per soft-min; bigger problems fill the GPU with one soft-min per launch (pre-packed columns, XCD grids)
-_ITER4_MAX_PAIRS = float(os.environ.get("GEOMLOSS_HIP_ITER4_MAX_PAIRS", "4e9"))   # measured: B x 4096^2 with B = 32..128 and N = 3e4 gain 5-13 %, 7e4+ lose
+_ITER4_MAX_PAIRS = 4e9   # measured: B x 4096^2 with B = 32..128 and N = 3e4 gain 5-13 %, 7e4+ lose
 _graphs = hip.GraphCache()
 
 
@@ -268,7 +268,7 @@ def set_iteration_fusion(enabled):
 # A given `diameter` says nothing reliable about the data (set_range): online losses of at least this many pairs per soft-min measure
 # the bounding box themselves — one small reduction and its read-back, < 1 % of such a loss — smaller ones stay on bf16 x 3, where
 # the host bounds the run time anyway and a synchronisation would cost more than the layout gains.
-_EXTENT_MIN_PAIRS = float(os.environ.get("GEOMLOSS_HIP_EXTENT_MIN_PAIRS", "2e8"))
+_EXTENT_MIN_PAIRS = 2e8
 
 
 def _extent_for_range(x, y, diameter, diameter_given, bounds_the_data=False):
@@ -423,8 +423,8 @@ def dense_is_cheaper(kept, N, M, Cr, Cc):
     return sparse > float(N) * float(M)
 
 
-# rows of a 2-wavefront workgroup of the block-sparse soft-min (GLHIP_FLAG_SMALL_ROW_BLOCKS); GEOMLOSS_HIP_SMALL_ROW_BLOCK=0: never hint
-_SMALL_ROW_BLOCK = int(os.environ.get("GEOMLOSS_HIP_SMALL_ROW_BLOCK", "64"))
+# rows of a 2-wavefront workgroup of the block-sparse soft-min (GLHIP_FLAG_SMALL_ROW_BLOCKS); 0: never hint
+_SMALL_ROW_BLOCK = 64
 
 
 def _goes_dense(truncate, eps, eps_last, N, M, Cr, Cc, kept_pairs):

@@ -63,8 +63,11 @@ extern "C" {
                                  instead of the per-workgroup-centred expansion. Slower, tighter. */
 #define GLHIP_FLAG_NO_MFMA 2  /* p=2 softmin / gaussian: form the exponents on the VALU instead of the matrix cores */
 #define GLHIP_FLAG_NO_SPLIT 4 /* never split the columns of a row over several workgroups (ignore the workspace) */
-#define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split */
-#define GLHIP_FLAG_XDL16 16   /* p=2 softmin forward / gaussian product: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 */
+#define GLHIP_FLAG_F32_MFMA 8 /* p=2 softmin forward: fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x3 split.  A/B only: compiled in
+                                 with `make AB=1`; the shipped library runs its default kernel (same results to rounding) */
+#define GLHIP_FLAG_XDL16 16   /* gaussian product: bf16x3 on 16x16x32 MFMAs (the previous tiling) instead of 32x32x16 — the tiling of the
+                                 gradient kernels, see GLHIP_FLAG_GRAD_FAMILY.  p=2 softmin forward: that tiling with `make AB=1` only
+                                 (A/B; the shipped library runs its default kernel) */
 #define GLHIP_FLAG_GRAD_FAMILY GLHIP_FLAG_XDL16 /* kernel products: round like the product of glhip_kernel_conv_fwd_grad of the same
                                  kind — gaussian: the 16x16x32 tiling above; laplacian / energy: explicit differences with |.| = m rsq(m)
                                  (bit-identical to that product).  For the other two terms of a kernel norm whose gradient is on. */
@@ -93,18 +96,14 @@ extern "C" {
                                   are (the generic explicit-difference kernel), e.g. for callers that hand in sorted clouds and their own ranges. */
 
 /* Environment variables read ONCE per process by the library itself (test / tuning knobs; everything else is an argument):
- *   GLHIP_FWD_NW = 4 | 8      force the workgroup height (wavefronts) of the bf16x3 forward kernels instead of the size heuristic
- *   GLHIP_ITER4_PRE_MIN = <p> glhip_sinkhorn_iter4 pre-packs the columns of its problems from <p> pairs per launch on (default 1e8)
- *   GLHIP_DIST_MULTI_MIN_COLS = <c> p = 1 glhip_sinkhorn_iter4 / _anneal / _extrapolate4: launches with fewer than 512 workgroups split their
- *                             columns down to <c> per split (default 128; 0: the size rule only)
- *   GLHIP_TINY_MULTI_PAIRS = <p> unbatched glhip_sinkhorn_iter4 / _anneal / _extrapolate4 launches of up to <p> rows x columns per problem run
- *                             without column splits, i.e. without a merge launch (default 5e6; 0: always the size rule)
- *   GLHIP_ITER4_SPLITS = <n>  glhip_sinkhorn_iter4 / _extrapolate4, D <= 3, p = 2: column splits per problem instead of the size rule
+ *   GLHIP_FWD_NW = 2 | 4 | 8  force the workgroup height (wavefronts) of the soft-min forward kernels instead of the size heuristic
+ *   GLHIP_PREPACK_MIN = <p>   pairs per launch from which the columns are split into matrix-core records once per launch (default 5e8)
  *   GLHIP_DIST_GUARD = <x>    near-pair threshold of the matrix-core distance kernels: pairs with d^2 < x |xs_i|^2 are re-evaluated
  *                             on explicit differences (default 2^-8; 1e30 = every pair, used by the tests to check the register
  *                             <-> column map; 0 = none)
  * They are latched in function-local statics on first use: the library keeps no other global state (re-entrant apart from the
- * thread-local error string). */
+ * thread-local error string).  (Seven more A/B knobs of rounds 3-5 — GLHIP_ITER4_PRE_MIN, _ITER4_SPLITS, _TINY_MULTI_PAIRS,
+ * _DIST_MULTI_MIN_COLS, _WQ_MIN_D, _XD_PRE, _H2_VIA_XD — were removed in round 6: their measured optimum is a constant now.) */
 
 /* error codes */
 #define GLHIP_OK 0
