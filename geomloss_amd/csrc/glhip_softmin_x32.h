@@ -253,11 +253,21 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         if (PRE) launch_centre<D, T>(prm.x, b, N, centre);
         else load_point<D, T>(prm.x, (long)b * N + row0, centre);
 
-        // block-sparse: the row chunks of a cluster of ~455 points are 256 + 199 rows, so one wavefront in sixteen owns no row —
-        // always the last one, i.e. always the same SIMD of its CU.  Rotating the wavefront -> rows assignment by the chunk index
-        // spreads those empty slots over the four SIMDs.
+        // block-sparse: the wavefront -> rows assignment is rotated by the chunk index (the empty slots of successive partial chunks
+        // fall on different SIMDs), and a chunk that fills at most half of the workgroup's row tiles shares each row tile between
+        // `cs` = 2 or 4 wavefronts, which take every cs-th column group of a tile and merge their (max, sum) pairs through LDS at the
+        // end.  A cluster of 530 rows is 4 chunks of 128 + 18 rows: until round 6 those 18 rows cost a fifth full chunk — one
+        // wavefront reducing, three staging and waiting — i.e. +25 % for 3.5 % more rows, on the ~30 % of the voxel clusters of a
+        // uniform cloud that exceed a multiple of the chunk height (tools/probe_sparse_ideal.py: 416-row clusters 0.61 of the VALU
+        // model against 0.76 for 384).
         const int wslot = SPARSE ? ((wave + bx) & (NW - 1)) : wave;
-        const int wave_row0 = row0 + wslot * kRowsPerWave;
+        int cs = 1;
+        if (SPARSE && RT == 1 && NW >= 4) {
+            const int tiles = (min(row_end, row0 + kRowsPerBlock) - row0 + 31) >> 5;      // row tiles of this pass
+            cs = tiles * 4 <= NW ? 4 : (tiles * 2 <= NW ? 2 : 1);
+        }
+        const int cpart = wslot & (cs - 1);                // this wavefront's share of the column groups: cpart, cpart + cs, ...
+        const int wave_row0 = row0 + (wslot / cs) * kRowsPerWave;
         uint4 Xlo[RT], Xhi[RT];
         float m[RT], ssum[RT];
 #pragma unroll
@@ -389,7 +399,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 if (!wave_active) continue;
 
                 const int nG = npad / 32;
-                int G0 = 0;
+                int G0 = cpart;
                 // one 32 x 32 block of exponents: column group G against row tile rt (`plain`: with n = 0, for the exact maxima)
                 auto block = [&](int G, int rt, bool plain) -> f32x16 {
                     if constexpr (H2) {
@@ -404,10 +414,10 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                     if constexpr (H2) Xlo[rt] = select_u4(half == 0, xd_with_n<L>(Xlo[rt], -mx), Xlo[rt]);
                     else if (half) Xhi[rt] = pack_negmax(mx);
                 };
-                if (first_group) {   // exact maximum over the first 32 columns
+                if (first_group && G0 < nG) {   // exact maximum over the first 32 columns (of this wavefront's share)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const f32x16 u = block(0, rt, false);      // n = 0 so far
+                        const f32x16 u = block(G0, rt, false);      // n = 0 so far
                         float um = max16(u);
                         um = fmaxf(um, __shfl_xor(um, 32, 64));
                         um = fmaxf(um, kFloor);
@@ -416,13 +426,13 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                         set_max(rt, um);
                     }
                     first_group = false;
-                    G0 = 1;
+                    G0 += cs;
                 }
 
                 float stmp[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
-                for (int G = G0; G < nG; ++G) {
+                for (int G = G0; G < nG; G += cs) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(block(G, rt, false));
                 }
@@ -431,7 +441,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                 for (int rt = 1; rt < RT; ++rt) smax = fmaxf(smax, stmp[rt]);
                 if (__any(!(smax < kSumThr))) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
-                    for (int G = G0; G < nG; ++G) {
+                    for (int G = G0; G < nG; G += cs) {
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) {
                             const f32x16 u = block(G, rt, true);
@@ -451,11 +461,35 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
             }
         }
 
-        if (wave_active) {
+        float sfin[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            sfin[rt] = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // both halves carry the same max
+            if (H2 && m[rt] <= kH2Floor * 0.98f) sfin[rt] = 0.f;  // a row still at the floor has seen no mass (glhip_softmin_xd.h)
+        }
+        if (cs > 1) {      // (workgroup-uniform) the wavefronts that shared a row tile merge their (max, sum) pairs through the tile buffer
+            __syncthreads();                                      // everybody is done with the last tile
+            float* red = reinterpret_cast<float*>(tileX);         // [wavefront slot][32 rows][max, sum]
+            if (half == 0) {
+                red[(wslot * 32 + l31) * 2] = m[0];
+                red[(wslot * 32 + l31) * 2 + 1] = sfin[0];
+            }
+            __syncthreads();
+            if (cpart == 0) {
+                for (int c = 1; c < cs; ++c) {
+                    const float m2 = red[((wslot + c) * 32 + l31) * 2], s2 = red[((wslot + c) * 32 + l31) * 2 + 1];
+                    const float mnew = fmaxf(m[0], m2);
+                    sfin[0] = sfin[0] * fast_exp2(m[0] - mnew) + s2 * fast_exp2(m2 - mnew);
+                    m[0] = mnew;
+                }
+            }
+            __syncthreads();                                      // (the next row pass stages into the same buffer)
+        }
+
+        if (wave_active && cpart == 0) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                float s = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);   // both halves carry the same max
-                if (H2 && m[rt] <= kH2Floor * 0.98f) s = 0.f;      // a row still at the floor has seen no mass (glhip_softmin_xd.h)
+                const float s = sfin[rt];
                 const int i = wave_row0 + rt * 32 + l31;
                 if (half == 0 && i < row_end) {
                     float xi[D];

@@ -39,3 +39,5 @@ run(512, 66, "66 runs of 7 clusters     ")
 run(455, 66, "66 runs of 7, 455 rows    ")
 run(455, 1, "one run, 455 rows         ")
 run(512, 66, "66 runs of 7, bf16 x 3    ", flags=0)
+for cs in (530, 480, 448, 416, 384):      # 4 x 128 + 18 rows; 3 x 128 + 96 / + 64 / + 32 / + 0 rows
+    run(cs, 1, f"one run, {cs} rows         ")
