@@ -131,7 +131,10 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     constexpr int kRowsPerBlock = NW * 32;             // 16 * kFwdRT = 32 rows per wavefront in all three kernels
     static_assert(kFwdRT == 2, "row tiling of the forward kernels");
     unsigned chunk_grid = 0;   // block-sparse: one workgroup per row chunk of kRowsPerBlock rows (build_row_chunks_kernel)
-    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid) : rg;
+    // 4 wavefronts on the 32x32x16 kernel, f16 x 2 layout: chunks of whole groups of 4 row tiles, leftover row tiles carried (glhip_softmin_x32.h)
+    // (profiles/r06_carried_tiles_ab.txt)
+    const int share = (KIND == FWD_X32 && NW == 4 && L == XL_F16X2 && n_ranges > 0) ? 1 : 0;
+    const Ranges rgc = n_ranges > 0 ? with_row_chunks(rg, n_ranges, N, kRowsPerBlock, sc.cb, st, chunk_grid, share) : rg;
     // the number of column splits is still derived from the number of row BLOCKS: deriving it from the (larger) chunk count
     // gives fewer, longer-lived workgroups and measured 3 % slower on uniform clusters (multiscale at 1e6: 258 vs 250 ms)
     const long row_blocks = n_ranges > 0 ? (long)n_ranges : (long)B * ((N + kRowsPerBlock - 1) / kRowsPerBlock);
@@ -146,6 +149,7 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     // block-sparse: small row clusters come with short column intervals (the reference's cluster_scale rule makes ~2000 clusters
     // whatever N is) — gather them into full tiles; clusters of hundreds of points already fill theirs
     sp.gather = (n_ranges > 0 && N / n_ranges < 128) ? 1 : 0;
+    sp.share = (share && rgc.chunks) ? 1 : 0;
 
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.

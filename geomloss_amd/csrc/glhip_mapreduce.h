@@ -34,6 +34,7 @@ struct SplitInfo {
     int xcd_grid_x;     // > 0: 1-D XCD-aware grid (see workgroup_coords); value = number of row blocks per batch item
     int xcd_blocks;     // XCD-aware grid: row blocks x batch items (workgroups per column split)
     int gather = 0;     // block-sparse forward kernel: tiles gather several short column intervals (glhip_softmin_x32.h: gather_tile)
+    int share = 0;      // block-sparse forward kernel, 4 wavefronts: the chunk table was built in share mode (build_row_chunks_kernel)
 };
 
 // Logical (row block, batch item, column split) of this workgroup.  Plain mode: the 3-D grid.  XCD-aware mode
@@ -111,7 +112,8 @@ __device__ __forceinline__ void column_interval(const Ranges& rg, int M, int q, 
 // only knows the bound T <= n_ranges + N / rows (valid for disjoint row blocks) and launches that many workgroups; the surplus
 // exits at once.  chunks[0] < 0 = "table too small, ignore it" (see the end of the kernel).
 static __global__ void __launch_bounds__(1024)
-build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int rows, int32_t* __restrict__ chunks, int capacity) {
+build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int rows, int32_t* __restrict__ chunks, int capacity,
+                        int share = 0) {
     __shared__ int scan[1024];
     __shared__ int carry;
     const int tid = threadIdx.x;
@@ -121,7 +123,17 @@ build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int 
         const int k = base + tid;
         int r0 = 0, r1 = 0;
         if (k < n_ranges) { r0 = ranges_i[2 * k]; r1 = ranges_i[2 * k + 1]; }
-        const int cnt = (r1 > r0) ? (r1 - r0 + rows - 1) / rows : 0;
+        int cnt = (r1 > r0) ? (r1 - r0 + rows - 1) / rows : 0;
+        // share (rows = 128 = 4 row tiles of 32; glhip_softmin_x32.h): a row block of nt > 4 row tiles gets W = nt / 4 chunks of exactly
+        // 4 tiles; of the rl = nt mod 4 tiles left over, min(rl, W) are reduced on the side by the workgroups of the first chunks
+        // (one each) and belong to no chunk; the others (W < rl: blocks of 5 - 7, 11 row tiles) form a trailing partial chunk
+        int full = cnt, skip = 0;      // chunks of `rows` rows; share: rows of the carried tiles, between the last full chunk and the trailing one
+        if (share && cnt > 1) {
+            const int nt = (r1 - r0 + 31) >> 5, W = nt >> 2, rl = nt - 4 * W, e = rl < W ? rl : W;
+            full = W;
+            skip = 32 * e;
+            cnt = W + (rl > e ? 1 : 0);
+        }
         scan[tid] = cnt;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {   // inclusive Hillis-Steele scan
@@ -135,8 +147,8 @@ build_row_chunks_kernel(const int32_t* __restrict__ ranges_i, int n_ranges, int 
             const int slot = first + c;
             if (slot < capacity) {
                 chunks[1 + 3 * slot] = k;
-                chunks[2 + 3 * slot] = r0 + c * rows;
-                chunks[3 + 3 * slot] = min(r1, r0 + (c + 1) * rows);
+                chunks[2 + 3 * slot] = r0 + c * rows + (c < full ? 0 : skip);
+                chunks[3 + 3 * slot] = c < full ? min(r1, r0 + (c + 1) * rows) : r1;
             }
         }
         __syncthreads();
@@ -275,11 +287,11 @@ static inline size_t chunk_table_bytes(int n_ranges, int N, int rows) {
 // Queues build_row_chunks_kernel for a reduction whose workgroups take `rows` rows and returns the ranges to hand to it
 // together with its grid.x; without a reserved table (no workspace) the launch keeps one workgroup per row block.
 static inline Ranges with_row_chunks(const Ranges& rg, int n_ranges, int N, int rows, const ChunkBuf& cb, hipStream_t stream,
-                                     unsigned& grid_x) {
+                                     unsigned& grid_x, int share = 0) {
     grid_x = (unsigned)n_ranges;
     const long bound = (long)n_ranges + N / rows;
     if (!cb.buf || cb.capacity < bound || n_ranges <= 0) return rg;
-    hipLaunchKernelGGL(build_row_chunks_kernel, dim3(1), dim3(1024), 0, stream, rg.ranges_i, n_ranges, rows, cb.buf, (int)bound);
+    hipLaunchKernelGGL(build_row_chunks_kernel, dim3(1), dim3(1024), 0, stream, rg.ranges_i, n_ranges, rows, cb.buf, (int)bound, share);
     Ranges out = rg;
     out.chunks = cb.buf;
     grid_x = (unsigned)bound;

@@ -233,6 +233,12 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
     constexpr int kPer = (kTile * NR) / kThreads;   // PRE: records one thread moves per tile
     static_assert((kTile * NR) % kThreads == 0, "tile / workgroup shape");
     constexpr float kFloor = H2 ? kH2Floor : kMinusHuge;      // the running maximum of a row that has seen no mass yet
+    // Block-sparse, 4 wavefronts: a workgroup may carry ONE leftover row tile of its row block besides its own 4 (SplitInfo::share,
+    // build_row_chunks_kernel): every wavefront reduces its own row tile against all the column groups of a tile and the leftover
+    // row tile against every 4th group — 1.25 row tiles of work per wavefront, none of them idle.  (Up to 3 leftover tiles per
+    // workgroup were tried: 22-25 more VGPRs per slot, 150 in all, 3 waves per SIMD.)
+    constexpr int XS = (SPARSE && RT == 1 && NW == 4 && L == XL_F16X2) ? 1 : 0;      // (bf16 x 3: 94 -> 122 VGPRs and spills; left alone)
+    constexpr int NS = RT + XS;                     // row-tile slots of a wavefront: [0, RT) its own, [RT, NS) the shared leftovers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,6 +250,28 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
 
     int row_begin, row_end, q_begin, q_end;
     block_extent<SPARSE>(rg, N, kRowsPerBlock, row_begin, row_end, q_begin, q_end, bx);
+    // share mode: a row block [r0, r1) of nt > 4 row tiles is cut into W = nt / 4 chunks of exactly 4 row tiles; of its last
+    // rl = nt - 4 W row tiles, the first min(rl, W) go one each to workgroups of the block's chunks and the others form a trailing partial chunk
+    int xb = 0, xe = 0;
+    if constexpr (XS > 0) {
+        if (sp.share && rg.chunks && rg.chunks[0] >= 0 && bx < rg.chunks[0]) {
+            const int kb = rg.chunks[1 + 3 * bx];
+            const int r0 = rg.ranges_i[2 * kb], r1 = rg.ranges_i[2 * kb + 1];
+            const int nt = (r1 - r0 + 31) >> 5;
+            if (nt > 4) {
+                // which chunks carry is scattered with the row block's index: workgroups go round the 8 XCDs by their linear id, and
+                // with "the first chunk of every block" equal blocks of 4 chunks sent all the 1.25-tile workgroups to XCDs 0 and 4
+                // (tools/probe_sparse_ideal.py, 530-row clusters: 26.3 ms against 22.8 without carrying)
+                const int W = nt >> 2, rl = nt - 4 * W, c = (row_begin - r0) >> 7;
+                const int t = (c + W - (int)((((unsigned)kb * 0x9E3779B1u) >> 16) % (unsigned)W)) % W;      // leftover tile of chunk c, if < rl
+                if (c < W && t < rl) {
+                    xb = r0 + 128 * W + 32 * t;
+                    xe = min(r1, xb + 32);
+                }
+            }
+        }
+    }
+    const int nx = XS > 0 ? (xe - xb + 31) >> 5 : 0;      // leftover row tiles of this workgroup (wave-uniform; > 0 only beside a full chunk)
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const uint4 kOnes = uint4{0x3F803F80u, 0x00003F80u, 0u, 0u};   // [1,1,1,0,...]: block 3 with n = 0
@@ -268,11 +296,17 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
         }
         const int cpart = wslot & (cs - 1);                // this wavefront's share of the column groups: cpart, cpart + cs, ...
         const int wave_row0 = row0 + (wslot / cs) * kRowsPerWave;
-        uint4 Xlo[RT], Xhi[RT];
-        float m[RT], ssum[RT];
+        uint4 Xlo[NS], Xhi[NS];
+        float m[NS], ssum[NS];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int i = min(wave_row0 + rt * 32 + l31, row_end - 1);
+        for (int rt = 0; rt < NS; ++rt) {
+            if (rt >= RT && rt - RT >= nx) {      // no such leftover tile: the slot is never touched
+                Xlo[rt] = Xhi[rt] = uint4{0u, 0u, 0u, 0u};
+                m[rt] = kFloor;
+                ssum[rt] = 0.f;
+                continue;
+            }
+            const int i = rt < RT ? min(wave_row0 + rt * 32 + l31, row_end - 1) : min(xb + (rt - RT) * 32 + l31, xe - 1);
             float xi[D];
             load_point<D, T>(prm.x, (long)b * N + i, xi);
             if constexpr (H2) {      // one operand: record `half` of [k,k,k,n1,n2,n3 | a_hi,a_hi,a_lo per coordinate], n = 0 for now
@@ -295,7 +329,7 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
             ssum[rt] = 0.f;
         }
         const bool wave_active = wave_row0 < row_end;
-        bool first_group = true;
+        bool first_group = true, first_shared = true;
 
         // PRE: the records of the next tile are fetched into registers while the current tile is consumed
         u32x4 pre[kPer];
@@ -414,49 +448,79 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
                     if constexpr (H2) Xlo[rt] = select_u4(half == 0, xd_with_n<L>(Xlo[rt], -mx), Xlo[rt]);
                     else if (half) Xhi[rt] = pack_negmax(mx);
                 };
+                auto first_exact = [&](int G, int rt) {     // the first group a slot sees: exact maximum over its 32 columns (n = 0 so far)
+                    const f32x16 u = block(G, rt, false);
+                    float um = max16(u);
+                    um = fmaxf(um, __shfl_xor(um, 32, 64));
+                    um = fmaxf(um, kFloor);
+                    m[rt] = um;
+                    ssum[rt] = sum_exp2_16(u, um);
+                    set_max(rt, um);
+                    if (XS > 0) __builtin_amdgcn_sched_barrier(0);      // one slot at a time: 16 result registers, not 16 per slot
+                };
+                auto group_exact = [&](int G, int rt) {     // one group with its exact maximum folded into the running pair
+                    const f32x16 u = block(G, rt, true);
+                    float um = max16(u);
+                    um = fmaxf(um, __shfl_xor(um, 32, 64));
+                    const float mnew = fmaxf(m[rt], um);
+                    ssum[rt] = ssum[rt] * fast_exp2(m[rt] - mnew) + sum_exp2_16(u, mnew);
+                    m[rt] = mnew;
+                    if (XS > 0) __builtin_amdgcn_sched_barrier(0);
+                };
                 if (first_group && G0 < nG) {   // exact maximum over the first 32 columns (of this wavefront's share)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const f32x16 u = block(G0, rt, false);      // n = 0 so far
-                        float um = max16(u);
-                        um = fmaxf(um, __shfl_xor(um, 32, 64));
-                        um = fmaxf(um, kFloor);
-                        m[rt] = um;
-                        ssum[rt] = sum_exp2_16(u, um);
-                        set_max(rt, um);
-                    }
+                    for (int rt = 0; rt < RT; ++rt) first_exact(G0, rt);
                     first_group = false;
                     G0 += cs;
                 }
-
-                float stmp[RT];
+                int GX0 = wslot;                // leftover row tiles: this wavefront's column groups are wslot, wslot + 4, ...
+                if (XS > 0 && nx > 0 && first_shared && GX0 < nG) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) stmp[rt] = 0.f;
+                    for (int rt = RT; rt < NS; ++rt)
+                        if (rt - RT < nx) first_exact(GX0, rt);
+                    first_shared = false;
+                    GX0 += 4;
+                }
+
+                float stmp[NS];
+#pragma unroll
+                for (int rt = 0; rt < NS; ++rt) stmp[rt] = 0.f;
                 for (int G = G0; G < nG; G += cs) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) stmp[rt] += sum_exp2_16(block(G, rt, false));
                 }
+                if (XS > 0 && nx > 0 && !first_shared) {
+                    for (int G = GX0; G < nG; G += 4) {
+#pragma unroll
+                        for (int rt = RT; rt < NS; ++rt)
+                            if (rt - RT < nx) {
+                                stmp[rt] += sum_exp2_16(block(G, rt, false));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                }
                 float smax = stmp[0];
 #pragma unroll
-                for (int rt = 1; rt < RT; ++rt) smax = fmaxf(smax, stmp[rt]);
+                for (int rt = 1; rt < NS; ++rt) smax = fmaxf(smax, stmp[rt]);
                 if (__any(!(smax < kSumThr))) {
                     // a term far above the lazy max arrived (or inf / NaN): redo the tile with exact per-group maxima
                     for (int G = G0; G < nG; G += cs) {
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            const f32x16 u = block(G, rt, true);
-                            float um = max16(u);
-                            um = fmaxf(um, __shfl_xor(um, 32, 64));
-                            const float mnew = fmaxf(m[rt], um);
-                            ssum[rt] = ssum[rt] * fast_exp2(m[rt] - mnew) + sum_exp2_16(u, mnew);
-                            m[rt] = mnew;
+                        for (int rt = 0; rt < RT; ++rt) group_exact(G, rt);
+                    }
+                    if (XS > 0 && nx > 0 && !first_shared) {
+                        for (int G = GX0; G < nG; G += 4) {
+#pragma unroll
+                            for (int rt = RT; rt < NS; ++rt)
+                                if (rt - RT < nx) group_exact(G, rt);
                         }
                     }
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) set_max(rt, m[rt]);
+                    for (int rt = 0; rt < NS; ++rt)      // (a leftover slot that has seen no group yet keeps n = 0 for its first, exact one)
+                        if (rt < RT || (rt - RT < nx && !first_shared)) set_max(rt, m[rt]);
                 } else {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) ssum[rt] += stmp[rt];
+                    for (int rt = 0; rt < NS; ++rt) ssum[rt] += stmp[rt];
                 }
             }
         }
@@ -486,36 +550,66 @@ __device__ __forceinline__ void softmin_fwd_x32_body(const SoftminParams<T>& prm
             __syncthreads();                                      // (the next row pass stages into the same buffer)
         }
 
+        auto write_row = [&](int i, float mrow, float s) {      // row i: running maximum of its exponents (without r_i) and their sum
+            float xi[D];
+            load_point<D, T>(prm.x, (long)b * N + i, xi);
+            float n2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float xt = xi[d] - centre[d];
+                n2 = __builtin_fmaf(xt, xt, n2);
+            }
+            const float mtot = __builtin_fmaf(-0.5f * prm.s2, n2, mrow);   // r_i + m
+            if (ns == 1) {
+                prm.out[(long)b * N + i] = finish_value(prm, (long)b * N + i, mtot + fast_log2(s));
+            } else {
+                float* dst = sp.workspace + split * sp.split_stride + ((long)b * N + i) * 2;
+                dst[0] = mtot;
+                dst[1] = s;
+            }
+        };
         if (wave_active && cpart == 0) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float s = sfin[rt];
                 const int i = wave_row0 + rt * 32 + l31;
-                if (half == 0 && i < row_end) {
-                    float xi[D];
-                    load_point<D, T>(prm.x, (long)b * N + i, xi);
-                    float n2 = 0.f;
+                if (half == 0 && i < row_end) write_row(i, m[rt], sfin[rt]);
+            }
+        }
+        if (XS > 0 && nx > 0) {     // (workgroup-uniform) leftover row tiles: the four wavefronts' (max, sum) pairs meet in the tile buffer
+            __syncthreads();                                      // everybody is done with the last tile
+            float* red = reinterpret_cast<float*>(tileX);         // [leftover tile][wavefront slot][32 rows][max, sum]
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const float xt = xi[d] - centre[d];
-                        n2 = __builtin_fmaf(xt, xt, n2);
-                    }
-                    const float mtot = __builtin_fmaf(-0.5f * prm.s2, n2, m[rt]);   // r_i + m
-                    if (ns == 1) {
-                        prm.out[(long)b * N + i] = finish_value(prm, (long)b * N + i, mtot + fast_log2(s));
-                    } else {
-                        float* dst = sp.workspace + split * sp.split_stride + ((long)b * N + i) * 2;
-                        dst[0] = mtot;
-                        dst[1] = s;
+            for (int rt = RT; rt < NS; ++rt) {
+                if (rt - RT < nx) {
+                    float sx = ssum[rt] + __shfl_xor(ssum[rt], 32, 64);      // (all 64 lanes take part in the exchange)
+                    if (H2 && m[rt] <= kH2Floor * 0.98f) sx = 0.f;
+                    if (half == 0) {
+                        red[(((rt - RT) * 4 + wslot) * 32 + l31) * 2] = m[rt];
+                        red[(((rt - RT) * 4 + wslot) * 32 + l31) * 2 + 1] = sx;
                     }
                 }
             }
+            __syncthreads();
+            if (wslot < nx && half == 0) {                        // wavefront slot s finishes leftover tile s
+                const float* mine = red + (wslot * 4 * 32 + l31) * 2;
+                float mm = mine[0], sm = mine[1];
+                for (int c = 1; c < 4; ++c) {
+                    const float m2 = mine[c * 64], s2 = mine[c * 64 + 1];
+                    const float mnew = fmaxf(mm, m2);
+                    sm = sm * fast_exp2(mm - mnew) + s2 * fast_exp2(m2 - mnew);
+                    mm = mnew;
+                }
+                const int i = xb + wslot * 32 + l31;
+                if (i < xe) write_row(i, mm, sm);
+            }
+            __syncthreads();                                      // (a next row pass would stage into the same buffer)
         }
     }
 }
 
+// (the block-sparse 4-wavefront f16 x 2 kernel carries one more row-tile slot: held to 5 wavefronts per SIMD, <= 96 VGPRs)
 template <int D, typename T, bool SPARSE, int RT, int NW, bool PRE = false, int L = XL_BF16X3>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, (SPARSE && RT == 1 && NW == 4 && L == XL_F16X2) ? 5 : 1)
 softmin_fwd_x32_kernel(SoftminParams<T> prm, Ranges rg, int N, int M, SplitInfo sp, PackedCols pk) {
     __shared__ uint4 tileX[fwd_tile(NW) * X32Layout<L>::NR];
     int bx, b, split;

@@ -88,7 +88,10 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         // difference of 1e-3 of their size and owe their agreement to a common rounding pattern, which a per-block mean disturbs.
         // The first row it stays.)
         load_point<D, T>(prm.x, (long)b * N + row0, centre);
-        const int wave_row0 = row0 + wave * kMfmaRowsPerWave;
+        // block-sparse: the wavefront -> rows map is rotated by the chunk index, so that the short or empty last wavefronts of the
+        // partial chunks of successive row blocks fall on different SIMDs (as in glhip_softmin_x32.h)
+        const int wslot = SPARSE ? ((wave + bx) & 3) : wave;
+        const int wave_row0 = row0 + wslot * kMfmaRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
 
         uint4 A[kMfmaRT];

@@ -474,6 +474,18 @@ def voxel_extent(count_values, voxel, pre_div=1.0):
 # voxel rule need 2e6: with 2^20 every pattern of a two-scale loss was counted first — three synchronisations and 0.3 ms of a
 # 6.2-ms loss at N = 1e5 (round 5).
 _RANGES_WORST_CASE_MAX = 1 << 22
+_ranges_budget = {}
+
+
+def _worst_case_intervals(dev):
+    """Largest worst-case interval count served without the counting pass on `dev`: _RANGES_WORST_CASE_MAX, lowered on devices where
+    the two buffers of one pattern (16 bytes per interval) would exceed 1/2048 of the memory (round-5 advice: a two-scale loss holds
+    up to six patterns at a time; on the 288 GB of an MI355X the cap stays 2^22 = 2 x 32 MB per pattern)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _ranges_budget:
+        total = torch.cuda.get_device_properties(key).total_memory
+        _ranges_budget[key] = int(max(total // 2048 // 16, 1 << 16))
+    return min(_RANGES_WORST_CASE_MAX, _ranges_budget[key])
 
 
 def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
@@ -493,7 +505,7 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
         head = (int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, Cc, D, int(p), float(thr),
                 ranges_rows.data_ptr(), ranges_cols.data_ptr())
         cap = max(Cr * ((Cc + 1) // 2), Cc * ((Cr + 1) // 2), 1)
-        if cap > _RANGES_WORST_CASE_MAX:
+        if cap > _worst_case_intervals(dev):
             totals = torch.empty(2, dtype=torch.int32, device=dev)
             _check(lib.glhip_block_ranges_count(*head, slices_r.data_ptr(), slices_c.data_ptr(), totals.data_ptr(), _stream(rows)), lib)
             counts = [int(v) for v in totals.tolist()]                   # the one host round trip of the big case

@@ -144,6 +144,12 @@ size_t glhip_workspace_bytes(int B, int N, int M, int D, int n_ranges);
  * round 5, for every DENSE launch of 4 <= D <= 16 (glhip_dist_xd.h: squared distances from the MFMA chain, pairs closer than 1/16 of
  * their offset from the cloud's centre re-evaluated exactly); everything else (D > 16, block-sparse p = 1 in D > 3, GLHIP_FLAG_NO_MFMA /
  * GLHIP_FLAG_DIRECT) on explicit differences.
+ * Accuracy of the matrix-core distances (p = 1; laplacian / energy products): the squared distance of a pair carries ~2^-23 t^2 R^2
+ * (t = log2(e) / eps, R = offset of the pair from the centre the launch subtracts), so the EXPONENT of a pair just above the near-pair
+ * threshold d = R / 16 is off by ~2^-20 t R — it grows like diameter / eps — while out = -eps log(...) is off by
+ * ~2^-20 log2(e) R <= 1.4e-6 diameter whatever eps is; a kernel VALUE of the products carries the relative error 2^-20 t R at the
+ * threshold (random sign), 2^-24 t R for pairs at distance R.  Measured at eps / diameter = 0.005 and 0.002, D = 4, 5, 9
+ * (tests/test_xd_kernels_gpu.py::test_distance_reductions_xd_small_blur).  GLHIP_DIST_GUARD raises the threshold.
  */
 int glhip_softmin_fwd(const void* x, const void* y, const float* h, float* out,
                       int B, int N, int M, int D, float eps, int p, int in_dtype,

@@ -222,6 +222,41 @@ def test_softmin_block_sparse_prepacked_path(cuda):
     assert np.isposinf(outs[0][~live]).all()
 
 
+def test_block_sparse_leftover_row_tiles_are_carried(cuda):
+    """f16 x 2 layout, 4-wavefront workgroups (round 6): a row block of nt > 4 row tiles of 32 is cut into nt / 4 chunks of exactly 4
+    tiles and its nt mod 4 leftover tiles ride with the workgroups of the first chunks, each shared column-group-wise by the four
+    wavefronts (glhip_softmin_x32.h, build_row_chunks_kernel share mode).  Row blocks of every nt from 1 to 23 with ragged last
+    tiles — 129 rows (1 carried row), 160, 161 (a carried tile AND a trailing chunk of one row), 225 (5 - 7 tiles: W = 1 < rl),
+    353 (11 tiles: W = 2 < rl = 3), 416, 455, 530, 737 — on dense-ish and very sparse column patterns, with / without column
+    splits, pre-packed or not, a lazy-max stress vector, against the C oracle; and the 16x16x32 kernel on the same ranges."""
+    rng = np.random.default_rng(61)
+    sizes_i = np.array([129, 5, 160, 161, 33, 225, 128, 256, 257, 353, 300, 416, 455, 96, 530, 640, 737, 1, 200], dtype=np.int64)
+    sizes_j = np.array([300, 40, 1, 700, 90, 513, 31, 260, 1200, 64], dtype=np.int64)
+    N, M, D = int(sizes_i.sum()), int(sizes_j.sum()), 3
+    x, y, h = _clouds(67, N, M, D)
+    ends_i, ends_j = np.cumsum(sizes_i), np.cumsum(sizes_j)
+    ri = np.stack([ends_i - sizes_i, ends_i], 1).astype(np.int32)
+    rj = np.stack([ends_j - sizes_j, ends_j], 1).astype(np.int32)
+    eps = 0.02
+    h_spiky = (np.arange(M) // 64 * 48.0).astype(np.float32)      # every tile overflows its speculative pass and is redone exactly
+    h_spiky[M // 2:] -= 3000.0
+    h_spiky[-3] = 5000.0
+    for density in (0.6, 0.12):
+        keep = rng.random((len(sizes_i), len(sizes_j))) < density
+        keep[:, 2] = True                                   # every row block reduces over something (a single column here)
+        keep[3, :] = False
+        keep[3, 6] = True                                   # 161 rows against 31 columns: fewer column groups than wavefronts
+        rg = from_matrix(torch.from_numpy(ri).to(cuda), torch.from_numpy(rj).to(cuda), torch.from_numpy(keep).to(cuda))
+        tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+        for hv in (h, h_spiky):
+            ref = oracle_c.softmin(eps, x, y, hv, 2, ranges=tup)
+            for flags in (hip.FLAG_F16X2, hip.FLAG_F16X2 | hip.FLAG_NO_SPLIT, hip.FLAG_F16X2 | hip.FLAG_PREPACK, hip.FLAG_XDL16):
+                out = hip.softmin(eps, _t(x, cuda), _t(y, cuda), _t(hv, cuda), p=2, ranges=rg, flags=flags).cpu().numpy()
+                assert np.isfinite(out).all(), flags
+                err = np.abs(out - ref)
+                assert err.max() < 2e-6 + 3e-6 * np.abs(ref).max(), (flags, density, int(err.argmax()))
+
+
 def test_block_sparse_very_uneven_row_blocks(cuda):
     """Row blocks of 1 ... 6000 rows (voxel clusters of a cloud sampled on a surface look like this): the launch cuts them
     into row chunks (build_row_chunks_kernel), one workgroup each.  Forward, gradient, gaussian product and gradient against

@@ -31,8 +31,9 @@ def test_sinkhorn_matches_reference(cuda, name, backend):
     rec = load_golden(name)
     a, x, b, y = _inputs(rec, cuda)
     L = SamplesLoss(backend=backend, **rec["kwargs"])(a, x, b, y)
-    # p=1: the reference's own fp32 run is 3e-4 off its fp64 run (cancellation in the dense cost); our
-    # kernels evaluate distances on differences, so they are compared with the fp64 reference.
+    # p=1: the reference's own fp32 run is 3e-4 off its fp64 run (cancellation in the dense cost); our kernels evaluate distances on
+    # differences (D <= 3 small launches, D > 16) or on the bf16 x 3 MFMA chain with near pairs re-evaluated on differences
+    # (glhip_dist_x32.h, glhip_dist_xd.h: ~2^-20 diameter on a potential), so they are compared with the fp64 reference.
     ref = "f64" if rec["kwargs"]["p"] == 1 and backend == "online" else "f32"
     # (dense fp32 p = 1 costs in D = 12: sqrt(|x|^2 + |y|^2 - 2 x.y) of terms of size 4 — the reference's own fp32 run is 6e-4 off its
     # fp64 run there, and two fp32 evaluations of that matrix (CPU there, GPU here) differ by 1.4e-4)

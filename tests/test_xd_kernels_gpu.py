@@ -416,6 +416,34 @@ def test_distance_reductions_xd_vs_oracle(cuda, D, N, M, B):
     assert np.abs(got - 0.5 * (prev + 0.8 * want)).max() < 2e-6 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("D", [4, 5, 9])
+@pytest.mark.parametrize("ratio", [0.005, 0.002])
+def test_distance_reductions_xd_small_blur(cuda, D, ratio):
+    """blur / diameter = 0.005 and 0.002 (round-5 advice): the squared distance of the MFMA chain carries ~2^-23 t^2 R^2, so the
+    EXPONENT of a pair just above the near-pair guard (d = R / 16) is off by ~2^-20 t R — it grows like diameter / blur — but a
+    potential is eps times the logarithm: its error stays ~2^-20 log2(e) R whatever the blur (the bound written in include/glhip.h).
+    Soft-min p = 1 on x against y and on x against itself (the debiasing term: one coincident pair per row, neighbours at every
+    distance), laplacian product: sampled rows against the chunked float64 oracle."""
+    N, M = 6000, 9000
+    x, y, h = _clouds(31 * D, N, M, D)
+    diam = math.sqrt(D)
+    eps = ratio * diam                                   # p = 1: eps = blur
+    h = (h * 0.1).astype(np.float32)
+    rows = np.unique(np.r_[0, N - 1, np.random.default_rng(2).integers(0, N, 150)])
+    bound = 2.0 ** -20 * 1.4427 * diam                   # the documented bound on a potential, 4x margin below
+    xt, yt = _t(x, cuda), _t(y, cuda)
+    f = hip.softmin(eps, xt, yt, _t(h, cuda), p=1).cpu().numpy()
+    assert np.abs(f[rows] - o64.softmin(eps, x, y, h, p=1, rows=rows, device=cuda)).max() < 4 * bound
+    hs = np.ascontiguousarray(h[:N])
+    f = hip.softmin(eps, xt, xt, _t(hs, cuda), p=1).cpu().numpy()
+    assert np.abs(f[rows] - o64.softmin(eps, x, x, hs, p=1, rows=rows, device=cuda)).max() < 4 * bound
+    # kernel products: the error of a kernel VALUE is relative (2^-20 t R at the guard, random sign); sums of 9000 of them
+    v = (np.random.default_rng(3).random(M) / M).astype(np.float32)
+    blur = 0.02 * diam                                   # (at ratio 0.002 a laplacian product of 9000 points is one or two terms)
+    k = hip.kernel_conv("laplacian", xt, yt, _t(v, cuda), blur).cpu().numpy()
+    assert relerr(k[rows], o64.kconv("laplacian", x, y, v, blur, rows=rows, device=cuda)) < 2e-5
+
+
 def test_distance_reductions_xd_many_columns_and_self_term(cuda):
     """70 001 columns (column splits + merge) and a self-term (x against x: every row has one coincident pair), D = 6, 100 sampled
     rows against the chunked float64 oracle."""
