@@ -32,10 +32,10 @@ ss.clusterize = timed("clusterize", ss.clusterize)
 ss.kernel_truncation = timed("kernel_truncation", ss.kernel_truncation)
 ss.extrapolate_samples = timed("extrapolate", ss.extrapolate_samples)
 o_soft, o_step = hip.softmin, hip.sinkhorn_step
-def softmin(eps, x_, y_, h, p=2, ranges=None, flags=0, plan=None):
-    return timed("fine block-sparse" if ranges is not None else f"dense N={x_.shape[-2]} M={y_.shape[-2]}", o_soft)(eps, x_, y_, h, p=p, ranges=ranges, flags=flags, plan=plan)
-def step(eps, x_, y_, logw, pot, prev, damping, p=2, ranges=None, flags=0, plan=None):
-    return timed("fine block-sparse" if ranges is not None else f"dense N={x_.shape[-2]} M={y_.shape[-2]}", o_step)(eps, x_, y_, logw, pot, prev, damping, p=p, ranges=ranges, flags=flags, plan=plan)
+def softmin(eps, x_, y_, h, **kw):
+    return timed("fine block-sparse" if kw.get("ranges") is not None else f"dense N={x_.shape[-2]} M={y_.shape[-2]}", o_soft)(eps, x_, y_, h, **kw)
+def step(eps, x_, y_, logw, pot, prev, damping, **kw):
+    return timed("fine block-sparse" if kw.get("ranges") is not None else f"dense N={x_.shape[-2]} M={y_.shape[-2]}", o_step)(eps, x_, y_, logw, pot, prev, damping, **kw)
 hip.softmin, hip.sinkhorn_step = softmin, step
 L = SamplesLoss("sinkhorn", p=2, blur=0.05, backend="multiscale")
 tot = []
