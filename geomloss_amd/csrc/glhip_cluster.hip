@@ -533,6 +533,15 @@ __global__ void kept_zero_kernel(unsigned long long* kept) {
     if (threadIdx.x < 3) kept[threadIdx.x] = 0;
 }
 
+// Small fills and copies as kernels of this library: the FIRST hipMemsetAsync / hipMemcpyAsync of a process loads the runtime's own
+// blit kernels — 110 ms inside the first glhip_block_ranges call of a two-scale loss (round 6, tools/first_call.py)
+__global__ void fill_i32_kernel(int32_t* dst, int n, int32_t v) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v;
+}
+__global__ void gather2_i32_kernel(int32_t* dst, const int32_t* a, const int32_t* b) {
+    if (threadIdx.x == 0) { dst[0] = *a; dst[1] = *b; }
+}
+
 __global__ void __launch_bounds__(64 * kKeptWaves) kept_pairs_kernel(KeepRule rule, int Cr, int Cc, const int32_t* __restrict__ ranges_rows,
                                                                     const int32_t* __restrict__ ranges_cols, unsigned long long* __restrict__ kept) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -615,7 +624,7 @@ int glhip_grid_cluster(const void* x, const float* weights, int N, int D, int in
     if (!n_clusters) return fail(GLHIP_EINVAL, "glhip_grid_cluster: NULL n_clusters");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (N == 0) {
-        (void)hipMemsetAsync(n_clusters, 0, 8 * sizeof(int32_t), st);
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, n_clusters, 8, 0);
         return GLHIP_OK;
     }
     if (!x || !perm || !ranges || !centroids || !weights_c || !workspace)
@@ -646,7 +655,7 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
     if (!totals) return fail(GLHIP_EINVAL, "glhip_block_ranges_count: NULL totals");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Cr == 0 || Cc == 0) {
-        (void)hipMemsetAsync(totals, 0, 2 * sizeof(int32_t), st);
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, totals, 2, 0);
         return GLHIP_OK;
     }
     const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
@@ -654,8 +663,7 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_rows, Cr, slices_rows);
     hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0LL, nullptr);
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
-    (void)hipMemcpyAsync(totals, slices_rows + (Cr - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(totals + 1, slices_cols + (Cc - 1), sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(gather2_i32_kernel, dim3(1), dim3(64), 0, st, totals, slices_rows + (Cr - 1), slices_cols + (Cc - 1));
     return check_launch("glhip_block_ranges_count");
 }
 
@@ -668,7 +676,7 @@ int glhip_block_ranges(int kind, const float* rows, const float* cols, const flo
     if (Cr == 0 || Cc == 0) return GLHIP_OK;
     if (!red_cols || !red_rows || !status) return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, status, 1, 0);
     const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
     // the CSR offsets double as the count buffers of the first pass
     hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0LL, status);

@@ -271,7 +271,11 @@ void launch_wsum_kernel(bool x32, bool pre, dim3 grid, hipStream_t st, const Wsu
         if (x32 && pre) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, true>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
         if (x32) { hipLaunchKernelGGL((wsum_x32_kernel<MODE, D, T, SPARSE, false>), grid, dim3(kWsumNW * 64), 0, st, prm, rg, N, M, sp, pk, pq); return; }
     }
-    hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
+    // block-sparse soft-min gradient / value + gradient: 2 row tiles x 8 wavefronts (119 VGPRs, 4 wavefronts per SIMD; the last
+    // wavefronts of a partial chunk own no rows and skip the arithmetic) — 42.2 -> 40.4 ms at N = 1e6; dense launches are faster on
+    // 4 x 4 (149 vs 160 ms), the gaussian modes indifferent (164 vs 163)
+    if constexpr (SPARSE && MODE == WS_SOFTMIN_BWD) hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE, 2, 8>), grid, dim3(512), 0, st, prm, rg, N, M, sp);
+    else hipLaunchKernelGGL((wsum_mfma_kernel<MODE, D, T, SPARSE>), grid, dim3(kBlock), 0, st, prm, rg, N, M, sp);
 }
 
 template <int MODE, int D, typename T, class MergeOp>

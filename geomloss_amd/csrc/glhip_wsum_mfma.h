@@ -60,9 +60,13 @@ template <int MODE, int D> struct WsumShape {
     static constexpr int kPart = (MODE == WS_SOFTMIN_BWD || MODE == WS_GAUSS_FWDGRAD) ? D + 1 : (MODE == WS_GAUSS_FWD ? 1 : D);
 };
 
-template <int MODE, int D, typename T, bool SPARSE>
-__global__ void __launch_bounds__(kBlock)
+// RT 16-row tiles per wavefront x NW wavefronts = 256 rows per workgroup in both shapes: (4, 4), or (2, 8) — half the accumulators
+// per lane, twice the wavefronts
+template <int MODE, int D, typename T, bool SPARSE, int RT = kMfmaRT, int NW = 4>
+__global__ void __launch_bounds__(NW * 64)
 wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
+    static_assert(RT * NW * 16 == kMfmaRowsPerBlock, "256 rows per workgroup");
+    constexpr int kMfmaRT = RT, kMfmaRowsPerWave = RT * 16, kBlock = NW * 64;      // (shadow the 4 x 4 constants of glhip_softmin_mfma.h)
     constexpr int NQ = WsumShape<MODE, D>::kNQ;
     constexpr int NA = WsumShape<MODE, D>::kNA;
     __shared__ uint4 tileX[(kTileX / 16) * 64];          // bf16 x 3 B operands, as in softmin_fwd_xdl_kernel
@@ -90,7 +94,7 @@ wsum_mfma_kernel(WsumParams<T> prm, Ranges rg, int N, int M, SplitInfo sp) {
         load_point<D, T>(prm.x, (long)b * N + row0, centre);
         // block-sparse: the wavefront -> rows map is rotated by the chunk index, so that the short or empty last wavefronts of the
         // partial chunks of successive row blocks fall on different SIMDs (as in glhip_softmin_x32.h)
-        const int wslot = SPARSE ? ((wave + bx) & 3) : wave;
+        const int wslot = SPARSE ? ((wave + bx) & (NW - 1)) : wave;
         const int wave_row0 = row0 + wslot * kMfmaRowsPerWave;
         const bool wave_active = wave_row0 < row_end;
 

@@ -474,18 +474,14 @@ def voxel_extent(count_values, voxel, pre_div=1.0):
 # voxel rule need 2e6: with 2^20 every pattern of a two-scale loss was counted first — three synchronisations and 0.3 ms of a
 # 6.2-ms loss at N = 1e5 (round 5).
 _RANGES_WORST_CASE_MAX = 1 << 22
-_ranges_budget = {}
 
 
 def _worst_case_intervals(dev):
-    """Largest worst-case interval count served without the counting pass on `dev`: _RANGES_WORST_CASE_MAX, lowered on devices where
-    the two buffers of one pattern (16 bytes per interval) would exceed 1/2048 of the memory (round-5 advice: a two-scale loss holds
-    up to six patterns at a time; on the 288 GB of an MI355X the cap stays 2^22 = 2 x 32 MB per pattern)."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _ranges_budget:
-        total = torch.cuda.get_device_properties(key).total_memory
-        _ranges_budget[key] = int(max(total // 2048 // 16, 1 << 16))
-    return min(_RANGES_WORST_CASE_MAX, _ranges_budget[key])
+    """Largest worst-case interval count served without the counting pass: 2^22 = 2 x 32 MB of address space per pattern, of which
+    the kernels touch the used part.  (A cap relative to the device's memory was tried after the round-5 advice:
+    ``torch.cuda.get_device_properties`` costs ~110 ms on its first call — the whole first-call budget of a two-scale loss — and
+    ``mem_get_info`` a driver round trip per pattern; the buffers are transient and come from torch's caching allocator.)"""
+    return _RANGES_WORST_CASE_MAX
 
 
 def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
