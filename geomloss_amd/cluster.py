@@ -121,6 +121,16 @@ def native_clustering_applies(x, labels=None):
             and x.dtype in (torch.float32, torch.bfloat16) and hip.library_available())
 
 
+def native_keep_rule_applies(x):
+    """``glhip_block_ranges`` / ``_kept_pairs`` evaluate the keep rule on fp32 copies of the coarse clouds and potentials: also for the
+    float64 coarse level of big two-scale losses (round 6) — a cluster pair within float32 rounding of the threshold may be decided
+    the other way than in float64, which is what the borderline clause of the parity tests is for (0 - 2 of 4.8e6 pairs at N = 1e6).
+    The dense float64 mask + Python interval walk it replaces cost 2 ms per loss and 130 - 400 ms on the first call."""
+    from . import hip
+    return (x.is_cuda and x.dim() == 2 and x.shape[1] <= 3 and x.shape[0] > 0
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float64) and hip.library_available())
+
+
 def clusterize_device_many(clouds, scale, pre_div=1.0, long_perm=True, extent=None):
     """:func:`clusterize_device` for several weighted clouds ``[(a, x), ...]`` with ONE host round trip for all their cluster counts
     (the two measures of a two-scale loss: one synchronisation instead of two).  ``long_perm=False``: the permutations stay int32,

@@ -22,7 +22,7 @@ import torch
 
 from . import hip
 from .cluster import (block_ranges_device, cluster_ranges_centroids, clusterize_device, clusterize_device_many, from_matrix,
-                      grid_cluster, kept_pairs_device, native_clustering_applies, swap_axes)
+                      grid_cluster, kept_pairs_device, native_clustering_applies, native_keep_rule_applies, swap_axes)
 from .sinkhorn_divergence import log_weights, log_weights_many, max_diameter, scaling_parameters, sinkhorn_cost, sinkhorn_loop
 from .utils import distances, squared_distances
 
@@ -450,7 +450,7 @@ def kernel_truncation_prefetch(calls, eps, truncate=None, cost=None, eps_last=No
     pending = []
     for C, C_t, f, g in calls:
         x, y = C[0], C_t[0]
-        ok = native_p is not None and native_clustering_applies(x)
+        ok = native_p is not None and native_keep_rule_applies(x)
         pending.append(kept_pairs_device("dual_slack", x, y, f, g, C[2], C[3], truncate * eps, p=native_p, defer=True) if ok else None)
     live = [t for t in pending if t is not None]
     values = iter(hip.read_back(*live)) if live else iter(())
@@ -468,7 +468,7 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
     x_, yd_, ranges_x_, ranges_y_, _ = C_xy_
     y_, xd_, _, _, _ = C_yx_
     native_p = getattr(cost, "glhip_exponent", None)     # the two built-in costs carry their exponent
-    if native_p is not None and native_clustering_applies(x):
+    if native_p is not None and native_keep_rule_applies(x):
         rule = ("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps)
         dense, small_x, small_y = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0],
                                               (lambda: kept) if kept is not None else (lambda: kept_pairs_device(*rule, p=native_p)))
