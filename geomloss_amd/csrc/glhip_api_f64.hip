@@ -9,8 +9,9 @@
 // LDS as (D + 1) doubles, a lazy running maximum per row, an inlined 20-instruction `exp` (round 6: see f64_kernel).  It exists for
 // callers who need the digits — the reference's hypothesis suite draws float64 half the time, `geomloss.ot` users land here.
 //
-// The fused entry points (half-step, one-launch iteration, one-pass value + gradient) have no float64 form: the host composes
-// (geomloss_amd/hip.py).  Semantics follow the fp32 kernels: the clamp sqrt(max(d^2, 1e-8)) of utils.py:61 for p = 1 /
+// Of the fused entry points the half-step has a float64 form (glhip_sinkhorn_step_f64, round 6: the float64 coarse level of big
+// two-scale losses and float64 `ot.solve_sample` calls are bound by their launch count); the one-launch iteration and the one-pass
+// value + gradient do not: the host composes (geomloss_amd/hip.py).  Semantics follow the fp32 kernels: the clamp sqrt(max(d^2, 1e-8)) of utils.py:61 for p = 1 /
 // laplacian (on x / blur) / energy, zero direction at clamped pairs, rows of an empty column set give -eps * (-inf) ... exactly
 // what `logsumexp` gives, rows outside every row block are left untouched.
 #include <cmath>
@@ -33,6 +34,10 @@ struct F64Params {
     double scale;         // eps | blur
     int p;                // cost exponent (soft-min modes)
     int kind;             // GLHIP_GAUSSIAN | LAPLACIAN | ENERGY (kernel modes)
+    // fused half-step (F64_SOFTMIN, glhip_sinkhorn_step_f64): s_j := s_j + pot_scale * pot_j,  out_i := alpha * softmin_i + beta * prev_i
+    const double* pot = nullptr;      // (B, M) or NULL
+    const double* prev = nullptr;     // (B, N) or NULL
+    double pot_scale = 0.0, alpha = 1.0, beta = 0.0;
 };
 
 constexpr int kF64Block = 256;
@@ -114,7 +119,9 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
                 __syncthreads();
                 for (int t = tid; t < n * (D + 1); t += kF64Block) {
                     const int c = t / (D + 1), d = t - c * (D + 1);
-                    tile[c * (DMAX + 1) + d] = (d < D) ? yb[(long)(j0 + c) * D + d] : sb[j0 + c];
+                    double v = (d < D) ? yb[(long)(j0 + c) * D + d] : sb[j0 + c];
+                    if (MODE == F64_SOFTMIN && d == D && prm.pot) v = fma(prm.pot[(long)b * M + j0 + c], prm.pot_scale, v);
+                    tile[c * (DMAX + 1) + d] = v;
                 }
                 __syncthreads();
                 if (!live) continue;
@@ -183,7 +190,10 @@ f64_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D) {
         if (!live || sub != 0) continue;
         const long idx = (long)b * N + i;
         if (MODE == F64_SOFTMIN) {
-            prm.out[idx] = (m > -INFINITY) ? -prm.scale * (m + log(ssum)) : INFINITY;      // empty / massless row: -eps * (-inf)
+            double f = (m > -INFINITY) ? -prm.scale * (m + log(ssum)) : INFINITY;      // empty / massless row: -eps * (-inf)
+            f *= prm.alpha;
+            if (prm.prev) f = fma(prm.beta, prm.prev[idx], f);
+            prm.out[idx] = f;
         } else if (MODE == F64_KCONV) {
             prm.out[idx] = ssum;
         } else {
@@ -248,7 +258,9 @@ f64_generic_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D, 
                     __syncthreads();
                     for (int t = tid; t < n * stride; t += kF64Block) {
                         const int c = t / stride, d = t - c * stride;
-                        gtile[t] = (d < D) ? yb[(long)(j0 + c) * D + d] : sb[j0 + c];
+                        double v = (d < D) ? yb[(long)(j0 + c) * D + d] : sb[j0 + c];
+                        if (MODE == F64_SOFTMIN && d == D && prm.pot) v = fma(prm.pot[(long)b * M + j0 + c], prm.pot_scale, v);
+                        gtile[t] = v;
                     }
                     __syncthreads();
                     if (!live) continue;
@@ -299,7 +311,10 @@ f64_generic_kernel(F64Params prm, Ranges rg, int n_ranges, int N, int M, int D, 
             }
             if (!live) continue;
             if (MODE == F64_SOFTMIN) {
-                prm.out[idx] = (m > -INFINITY) ? -prm.scale * (m + log(ssum)) : INFINITY;
+                double f = (m > -INFINITY) ? -prm.scale * (m + log(ssum)) : INFINITY;
+                f *= prm.alpha;
+                if (prm.prev) f = fma(prm.beta, prm.prev[idx], f);
+                prm.out[idx] = f;
             } else if (MODE == F64_KCONV) {
                 prm.out[idx] = ssum;
             } else {
@@ -361,6 +376,21 @@ int glhip_softmin_fwd_f64(const double* x, const double* y, const double* h, dou
     if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_softmin_fwd_f64: p must be 1 or 2 (got %d)", p);
     const F64Params prm{x, y, h, nullptr, nullptr, out, eps, p, 0};
     return launch_f64<F64_SOFTMIN>("glhip_softmin_fwd_f64", prm, ranges_i, slices_i, redranges_j, n_ranges, B, N, M, D, stream);
+}
+
+int glhip_sinkhorn_step_f64(const double* x, const double* y, const double* logw, const double* pot, const double* prev, double* out,
+                            int B, int N, int M, int D, double eps, double damping, int p, const int32_t* ranges_i,
+                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* stream) {
+    if (!(eps > 0.0)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step_f64: eps must be > 0");
+    if (p != 1 && p != 2) return fail(GLHIP_EUNSUPPORTED, "glhip_sinkhorn_step_f64: p must be 1 or 2 (got %d)", p);
+    if (prev && prev == out) return fail(GLHIP_EINVAL, "glhip_sinkhorn_step_f64: out must not alias prev");
+    F64Params prm{x, y, logw, nullptr, nullptr, out, eps, p, 0};
+    prm.pot = pot;
+    prm.pot_scale = 1.0 / eps;
+    prm.prev = prev;
+    prm.alpha = prev ? 0.5 * damping : damping;
+    prm.beta = 0.5;
+    return launch_f64<F64_SOFTMIN>("glhip_sinkhorn_step_f64", prm, ranges_i, slices_i, redranges_j, n_ranges, B, N, M, D, stream);
 }
 
 int glhip_softmin_bwd_x_f64(const double* x, const double* y, const double* h, const double* out, const double* grad_out, double* grad_x,

@@ -69,6 +69,7 @@ _c_double = ctypes.c_double
 SIGNATURES.update({
     # float64 reductions (glhip_api_f64.hip): every array is double; no workspace, no flags
     "glhip_softmin_fwd_f64": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_double, _c_int] + _RANGES + [_vp]),
+    "glhip_sinkhorn_step_f64": (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_int, _c_int, _c_double, _c_double, _c_int] + _RANGES + [_vp]),
     "glhip_softmin_bwd_x_f64": (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_int, _c_int, _c_double, _c_int] + _RANGES + [_vp]),
     "glhip_kernel_conv_fwd_f64": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_double] + _RANGES + [_vp]),
     "glhip_kernel_conv_bwd_x_f64": (_c_int, [_c_int] + [_vp] * 5 + [_c_int, _c_int, _c_int, _c_int, _c_double] + _RANGES + [_vp]),
@@ -248,6 +249,14 @@ def sinkhorn_step_raw(x, y, logw, pot, prev, eps, damping, p=2, ranges=None, fla
     lib = load_library()
     B, N, D = x.shape
     M = y.shape[1]
+    if is_f64(x):      # every array double (glhip_sinkhorn_step_f64): no workspace, no flags
+        out = torch.empty((B, N), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.glhip_sinkhorn_step_f64(x.data_ptr(), y.data_ptr(), logw.data_ptr(), None if pot is None else pot.data_ptr(),
+                                             None if prev is None else prev.data_ptr(), out.data_ptr(), B, N, M, D, float(eps),
+                                             float(damping), int(p), *_range_args(ranges, B), _stream(x))
+        _check(rc, lib)
+        return out
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ws, ws_args = _workspace(lib, x, B, N, M, D, ranges)
@@ -979,7 +988,15 @@ def sinkhorn_step(eps, x, y, logw, pot, prev, damping, p=2, ranges=None, flags=0
 
     x: (N,D)|(B,N,D), y: (M,D)|(B,M,D); logw, pot: (M,)|(B,M) (pot may be None); prev: (N,)|(B,N) or None.
     Returns fp32 (N,)|(B,N).  Used by the drivers inside the no-grad part of ``sinkhorn_loop``."""
-    if not fused_step_applies(x.shape[-1], p, flags, ranges is not None) or is_f64(x):      # (float64 clouds: the double-precision kernels have no fused form)
+    if is_f64(x) and p in (1, 2):      # float64 clouds: the fused double-precision half-step (any D, dense / batched / block-sparse)
+        xb, yb, lw, batched = _as_batched(_points(x.detach(), "x", allow_f64=True), _points(y.detach(), "y", allow_f64=True),
+                                          logw.detach().double().contiguous())
+        B = xb.shape[0]
+        pt = None if pot is None else pot.detach().double().contiguous().reshape(B, -1)
+        pv = None if prev is None else prev.detach().double().contiguous().reshape(B, -1)
+        out = sinkhorn_step_raw(xb, yb.double(), lw, pt, pv, eps, damping, p, ranges, 0)
+        return out if batched else out.view(-1)
+    if not fused_step_applies(x.shape[-1], p, flags, ranges is not None) or is_f64(x):
         with torch.no_grad():
             h = _vec(logw, x) if pot is None else _vec(logw, x) + _vec(pot, x).reshape(logw.shape) / eps
             ft = damping * softmin(eps, x.detach(), y.detach(), h, p=p, ranges=ranges, flags=flags)

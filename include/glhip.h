@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 115 /* 0.1.15 */
+#define GLHIP_VERSION 116 /* 0.1.16 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -422,10 +422,16 @@ int glhip_block_ranges_kept_pairs(int kind, const float* rows, const float* cols
  * vector / weights, gradients, outputs — is `double`; same argument meaning, ranges convention and semantics (clamp of
  * utils.py:61, zero direction at clamped pairs) as glhip_softmin_fwd / glhip_softmin_bwd_x / glhip_kernel_conv_fwd /
  * glhip_kernel_conv_bwd_x above; any D up to 4095 (D > 16 since round 5: run-time coordinate loops, slower); no workspace, no flags.
- * One thread per row, explicit differences, no matrix cores: ~3-4e11 pairs/s, for callers who need the digits.  The fused entry points (half-step,
- * iteration, value + gradient) have no float64 form: compose these. */
+ * 1 to 64 threads per row, explicit differences, no matrix cores: ~5e11 pairs/s, for callers who need the digits.  Of the fused entry points
+ * only the half-step has a float64 form (below); iteration and value + gradient: compose these. */
 int glhip_softmin_fwd_f64(const double* x, const double* y, const double* h, double* out, int B, int N, int M, int D, double eps, int p,
                           const int32_t* ranges_i, const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* stream);
+/* glhip_sinkhorn_step in double precision (round 6): out_i = damping * t_i (prev == NULL) or (prev_i + damping * t_i) / 2, with
+ * t = soft-min(eps, C(x,y), logw + pot / eps) (pot == NULL: logw alone); out must not alias prev.  One launch instead of the soft-min
+ * and five elementwise float64 torch kernels per half-step of sinkhorn_divergence.py:461-465,480-493. */
+int glhip_sinkhorn_step_f64(const double* x, const double* y, const double* logw, const double* pot, const double* prev, double* out,
+                            int B, int N, int M, int D, double eps, double damping, int p, const int32_t* ranges_i,
+                            const int32_t* slices_i, const int32_t* redranges_j, int n_ranges, void* stream);
 int glhip_softmin_bwd_x_f64(const double* x, const double* y, const double* h, const double* out, const double* grad_out, double* grad_x,
                             int B, int N, int M, int D, double eps, int p, const int32_t* ranges_i, const int32_t* slices_i,
                             const int32_t* redranges_j, int n_ranges, void* stream);

@@ -65,6 +65,47 @@ def test_f64_kernel_products_and_gradients_vs_c_oracle(cuda, kind, D):
     assert relerr(gx.cpu().numpy(), refg) < 1e-11
 
 
+@pytest.mark.parametrize("D", [2, 3, 9, 20])
+@pytest.mark.parametrize("p", [2, 1])
+def test_f64_fused_half_step_vs_c_oracle(cuda, D, p):
+    """``glhip_sinkhorn_step_f64`` (round 6): out = damping * softmin(eps, C, logw + pot / eps), averaged with ``prev`` when given —
+    one launch — against the float64 C oracle at 1e-12: dense, batched, block-sparse; -inf log-weights (columns without mass);
+    small row counts (64 threads per row) and larger ones."""
+    rng = np.random.default_rng(7 * D + p)
+    eps, damping = (0.05 if p == 2 else 0.1), 0.8
+    for N, M, B in ((40, 700, None), (1500, 300, None), (130, 257, 3)):
+        x, y, logw = _clouds(D + N, N, M, D, B)
+        logw = np.log(rng.random(logw.shape) / M)
+        logw[..., ::9] = -np.inf
+        pot = rng.standard_normal(logw.shape) * 0.05
+        prev = rng.standard_normal(logw.shape[:-1] + (N,))
+        bs = [None] if B is None else range(B)
+        sel = (lambda a, b: a if b is None else a[b])
+        soft = np.stack([oracle_c.softmin(eps, sel(x, b), sel(y, b), sel(logw, b) + sel(pot, b) / eps, p) for b in bs]).reshape(prev.shape)
+        soft0 = np.stack([oracle_c.softmin(eps, sel(x, b), sel(y, b), sel(logw, b), p) for b in bs]).reshape(prev.shape)
+        xt, yt, lw, pt, pv = (_t(a, cuda) for a in (x, y, logw, pot, prev))
+        got = hip.sinkhorn_step(eps, xt, yt, lw, pt, pv, damping, p=p)
+        assert got.dtype == torch.float64 and relerr(got.cpu().numpy(), 0.5 * (prev + damping * soft)) < 1e-12
+        got = hip.sinkhorn_step(eps, xt, yt, lw, pt, None, damping, p=p)
+        assert relerr(got.cpu().numpy(), damping * soft) < 1e-12
+        got = hip.sinkhorn_step(eps, xt, yt, lw, None, None, damping, p=p)
+        assert relerr(got.cpu().numpy(), damping * soft0) < 1e-12
+    # block-sparse, with a row block that reduces over nothing (+inf there, like the soft-min itself)
+    N, M = 230, 260
+    x, y, logw = _clouds(3 * D, N, M, D)
+    pot, prev = rng.standard_normal(M) * 0.05, rng.standard_normal(N)
+    ri = np.array([[0, 100], [100, 140], [140, 230]], np.int32)
+    rj = np.array([[0, 90], [90, 200], [200, 260]], np.int32)
+    keep = np.array([[1, 0, 1], [0, 0, 0], [1, 1, 0]], bool)
+    rg = from_matrix(_t(ri, cuda), _t(rj, cuda), _t(keep, cuda))
+    tup = tuple(t.cpu().numpy() for t in (rg.ranges_i, rg.slices_i, rg.redranges_j))
+    want = 0.5 * (prev + damping * oracle_c.softmin(eps, x, y, logw + pot / eps, p, ranges=tup))
+    got = hip.sinkhorn_step(eps, _t(x, cuda), _t(y, cuda), _t(logw, cuda), _t(pot, cuda), _t(prev, cuda), damping, p=p, ranges=rg).cpu().numpy()
+    live = np.isfinite(want)
+    assert (~live).sum() == 40 and np.isposinf(got[~live]).all()
+    assert relerr(got[live], want[live]) < 1e-12
+
+
 def test_f64_block_sparse_with_an_empty_row_block(cuda):
     rng = np.random.default_rng(17)
     N, M, D = 900, 1100, 3
