@@ -446,6 +446,24 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
         const long fit_pre = (sc.ws && sc.bytes > packed_bytes + 256) ? (long)((sc.bytes - packed_bytes - 256) / per_split) : 0;
         const bool pre = NW == 8 && allow_pre && sc.prepack((double)B * N * M) && fit_pre >= 8;
         const int nx = pre ? xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0) : xcd_splits((long)gx * B, M, kXdSlots, fit);
+        if constexpr (NW == 8) {
+            // packed columns that fit every XCD's L2: any number of splits on the plain 3-D grid (free_splits), when that fills the
+            // chip's rounds better than the multiple of 8 (BASELINE config 2, online N = M = 1e5: 13 splits instead of 32: 0.937 -> 0.896 ms
+            // per soft-min, 35.3 -> 34.2 ms per loss; N = 7e4: 0.489 -> 0.439 ms)
+            double eff_free = 0.0;
+            const int nf = (pre && (double)M * S::NBP * 16.0 <= 3.5e6) ? free_splits((long)gx * B, M, kXdSlots, fit_pre, &eff_free) : 0;
+            const double wx = (double)gx * B * nx / (double)kXdSlots;
+            const double eff_x = wx / (double)(((long)gx * B * nx + kXdSlots - 1) / kXdSlots);
+            if (nf >= 2 && nf != nx && eff_free > eff_x + 0.02) {
+                sp.n_splits = nf;
+                const size_t part_bytes = (((size_t)nf * per_split) + 255) & ~(size_t)255;
+                pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
+                hipLaunchKernelGGL((xd_pack_kernel<MODE, D, T, L>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
+                hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, true, L>), dim3(gx, B, nf), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
+                hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
+                return;
+            }
+        }
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
             sp.n_splits = nx;

@@ -266,6 +266,24 @@ static inline int xcd_splits(long row_blocks, int M, long slots, long max_by_wor
     return best;
 }
 
+// Mid-size dense launches whose packed columns fit the L2 of EVERY XCD at once (<= 3.5 MB: M = 1e5 at 32 bytes per column) need no
+// XCD-aware placement, so the number of splits need not be a multiple of 8: the smallest ns in [4, 32] (>= 2048 columns per split)
+// that fills its last round of resident workgroups to >= 97 %, else the best.  N = M = 1e5, 196 row blocks of 512 rows on 512
+// slots: ns = 32 is 12.25 rounds spread over 13 (0.94) with 6 tiles per workgroup; ns = 13 is 4.98 rounds over 5 with 15 tiles.
+static inline int free_splits(long row_blocks, int M, long slots, long max_by_workspace, double* eff_out) {
+    int best = 0;
+    double best_eff = 0.0;
+    for (int ns = 4; ns <= 32; ++ns) {
+        if (ns > max_by_workspace || (long)M / ns < 2048) break;
+        const double w = (double)row_blocks * ns / (double)slots;
+        const double eff = w / (double)((row_blocks * ns + slots - 1) / slots);
+        if (eff >= 0.97) { best = ns; best_eff = eff; break; }
+        if (eff > best_eff + 0.01) { best_eff = eff; best = ns; }
+    }
+    if (eff_out) *eff_out = best_eff;
+    return best;
+}
+
 // ... and when the columns are pre-packed (64 bytes each), enough splits for one split's records to stay resident in the
 // 4 MB L2 of the XCD that streams them (workgroup_coords runs one split per XCD at a time).
 static inline int xcd_splits_prepacked(long row_blocks, int M, long slots, long max_by_workspace, double bytes_per_column = 64.0) {
