@@ -438,32 +438,38 @@ void launch_xd_cfg(const SoftminParams<T>& prm, const typename MergeOp::Params& 
     const int gx = (N + kRows - 1) / kRows;
     const dim3 merge_grid((N + kBlock - 1) / kBlock, B, 1);
     const XdPacked none{nullptr, 0};
-    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD at a time (workgroup_coords)
-        // pre-packed columns (glhip_softmin_xd.h): the records of all columns once, in workspace behind the split partials
-        XdPacked pk{nullptr, (long)((M + 31) / 32) * S::kGroupRecs};
-        const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
-        constexpr bool allow_pre = true;      // (A/B knob GLHIP_XD_PRE of rounds 4-5: pre-packed columns won, the knob is gone)
-        const long fit_pre = (sc.ws && sc.bytes > packed_bytes + 256) ? (long)((sc.bytes - packed_bytes - 256) / per_split) : 0;
-        const bool pre = NW == 8 && allow_pre && sc.prepack((double)B * N * M) && fit_pre >= 8;
-        const int nx = pre ? xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0) : xcd_splits((long)gx * B, M, kXdSlots, fit);
-        if constexpr (NW == 8) {
-            // packed columns that fit every XCD's L2: any number of splits on the plain 3-D grid (free_splits), when that fills the
-            // chip's rounds better than the multiple of 8 (BASELINE config 2, online N = M = 1e5: 13 splits instead of 32: 0.937 -> 0.896 ms
-            // per soft-min, 35.3 -> 34.2 ms per loss; N = 7e4: 0.489 -> 0.439 ms)
+    // pre-packed columns (glhip_softmin_xd.h): the records of all columns once, in workspace behind the split partials
+    XdPacked pk{nullptr, (long)((M + 31) / 32) * S::kGroupRecs};
+    const size_t packed_bytes = (size_t)B * (size_t)pk.stride * sizeof(uint4);
+    const long fit_pre = (sc.ws && sc.bytes > packed_bytes + 256) ? (long)((sc.bytes - packed_bytes - 256) / per_split) : 0;
+    const bool pre = NW == 8 && sc.prepack((double)B * N * M) && fit_pre >= 8;      // (A/B knob GLHIP_XD_PRE of rounds 4-5: pre-packed columns won)
+    if constexpr (NW == 8) {
+        // Packed columns that fit every XCD's L2 (<= 3.5 MB: M = 1e5 at 32 bytes per column) need no XCD-aware placement: any number
+        // of splits, on the plain 3-D grid, chosen to fill the chip's rounds of resident workgroups (free_splits).  BASELINE config 2,
+        // online N = M = 1e5: 13 splits instead of 32: 0.937 -> 0.896 ms per soft-min, 35.3 -> 34.2 ms per loss; N = 7e4: 0.489 -> 0.439 ms.
+        // From M = 8192 (below 65536 the launch used to pack its columns per workgroup, on up to 32 splits: raw soft-mins at N = M = 5e4,
+        // D = 4 / 5 / 8: 0.318 / 0.402 / 0.396 -> 0.280 / 0.303 / 0.300 ms).
+        if (n_ranges == 0 && sc.allow_split && pre && M >= 8192 && (double)M * S::NBP * 16.0 <= 3.5e6) {
             double eff_free = 0.0;
-            const int nf = (pre && (double)M * S::NBP * 16.0 <= 3.5e6) ? free_splits((long)gx * B, M, kXdSlots, fit_pre, &eff_free) : 0;
-            const double wx = (double)gx * B * nx / (double)kXdSlots;
-            const double eff_x = wx / (double)(((long)gx * B * nx + kXdSlots - 1) / kXdSlots);
-            if (nf >= 2 && nf != nx && eff_free > eff_x + 0.02) {
+            const int nf = free_splits((long)gx * B, M, kXdSlots, fit_pre, &eff_free);
+            double eff_x = 0.0;
+            if (M >= 65536) {
+                const int nx8 = xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0);
+                eff_x = ((double)gx * B * nx8 / (double)kXdSlots) / (double)(((long)gx * B * nx8 + kXdSlots - 1) / kXdSlots);
+            }
+            if (nf >= 1 && eff_free > eff_x + 0.02) {
                 sp.n_splits = nf;
-                const size_t part_bytes = (((size_t)nf * per_split) + 255) & ~(size_t)255;
+                const size_t part_bytes = (((size_t)(nf > 1 ? nf : 0) * per_split) + 255) & ~(size_t)255;
                 pk.rec = reinterpret_cast<uint4*>(static_cast<char*>(sc.ws) + part_bytes);
                 hipLaunchKernelGGL((xd_pack_kernel<MODE, D, T, L>), dim3((M + 31 + kBlock) / kBlock, B, 1), dim3(kBlock), 0, st, prm, N, M, pk);
                 hipLaunchKernelGGL((xd_fwd_kernel<MODE, D, T, false, RT, NW, true, L>), dim3(gx, B, nf), dim3(NW * 64), 0, st, prm, rg, N, M, sp, pk);
-                hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
+                if (nf > 1) hipLaunchKernelGGL((merge_kernel<MergeOp, false>), merge_grid, dim3(kBlock), 0, st, mprm, rg, N, sp);
                 return;
             }
         }
+    }
+    if (n_ranges == 0 && sc.allow_split && fit >= 8 && M >= 65536) {   // one column split per XCD at a time (workgroup_coords)
+        const int nx = pre ? xcd_splits_prepacked((long)gx * B, M, kXdSlots, fit_pre, S::NBP * 16.0) : xcd_splits((long)gx * B, M, kXdSlots, fit);
         const long total = (long)gx * B * nx;
         if (total < (1L << 31)) {
             sp.n_splits = nx;
@@ -999,6 +1005,8 @@ int softmin_typed(const void* x, const void* y, const float* h, float* out, cons
             constexpr bool via_xd = true;
             // (block-sparse launches through this kernel, packing their tiles on the fly in 512-row workgroups: 281 vs 244 ms per two-scale
             // loss at 1e6, round 6)
+            // (mid-size launches, 16384 <= M < 65536, through this kernel with pre-packed columns and a free split count: 0.164 -> 0.191 ms
+            // at N = M = 4e4, 0.242 -> 0.250 at 5e4, round 6: they stay on the x32 kernel)
             if (via_xd && p == 2 && sc.h2 && !direct && mfma && xdl == FWD_X32 && n_ranges == 0 && M >= 65536 && (double)B * N * M >= 5e8) {
                 if (D == 1) launch_xd_l<XD_SOFTMIN, 1, T, SoftminFwdOp<1, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);
                 else if (D == 2) launch_xd_l<XD_SOFTMIN, 2, T, SoftminFwdOp<2, 2, false, 1, T>, XL_F16X2>(prm, prm, rg, n_ranges, B, N, M, sc, st);

@@ -68,6 +68,28 @@ def test_softmin_fwd_large_launch_paths(cuda, D, N, M):
     assert np.abs(h2[rows] - ref).max() < _tol(ref, D) and np.abs(h2 - out).max() < 2 * _tol(ref, D)
 
 
+@pytest.mark.parametrize("D,N,M", [(3, 33_000, 66_001), (2, 40_000, 100_003), (1, 70_000, 80_000)])
+def test_mid_size_dense_launches_with_a_free_number_of_splits(cuda, D, N, M):
+    """f16 x 2 layout, D <= 3, >= 32768 rows, 65536 <= M with all packed columns (32 bytes each) inside one XCD's L2 (<= 3.5 MB): the
+    launch takes the split count that fills the chip's rounds of resident workgroups (glhip_mapreduce.h: free_splits — 23 splits
+    for 65 row blocks of 512 rows here, 13 at N = M = 1e5), not a multiple of 8, on the plain 3-D grid with pre-packed columns.
+    Soft-min and fused half-step: sampled rows against the float64 oracle, every row against the bf16 x 3 launch of the same call."""
+    x, y, h = _clouds(11 * D + 5, N, M, D)
+    h[-3:] += 25.0                                   # late maxima in the last, short split
+    eps = 0.07**2
+    rows = np.unique(np.r_[0, 511, 512, N - 1, np.random.default_rng(3).integers(0, N, 100)])
+    xt, yt, ht = _t(x, cuda), _t(y, cuda), _t(h, cuda)
+    ref = o64.softmin(eps, x, y, h, rows=rows, device=cuda)
+    out = hip.softmin(eps, xt, yt, ht, flags=hip.FLAG_F16X2)
+    assert np.abs(out.cpu().numpy()[rows] - ref).max() < _tol(ref, D)
+    assert (out - hip.softmin(eps, xt, yt, ht)).abs().max().item() < 2 * _tol(ref, D)
+    pot = _t((np.random.default_rng(4).standard_normal(M) * 0.05).astype(np.float32), cuda)
+    prev = _t(np.random.default_rng(5).standard_normal(N).astype(np.float32), cuda)
+    fused = hip.sinkhorn_step(eps, xt, yt, ht, pot, prev, 0.8, flags=hip.FLAG_F16X2)
+    unfused = 0.5 * (prev + 0.8 * hip.softmin(eps, xt, yt, ht + pot / eps, flags=hip.FLAG_F16X2))
+    assert (fused - unfused).abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("D,N,M", [(4, 33_000, 70_001), (8, 34_000, 66_000), (13, 33_333, 65_537), (16, 33_000, 70_001)])
 def test_prepacked_columns_and_lds_dma_path(cuda, D, N, M):
     """Big dense launches (>= 5e8 pairs, >= 32768 rows, M >= 65536: 8-wavefront workgroups on the XCD-aware grid) run on PRE-PACKED
