@@ -188,7 +188,7 @@ def kept_pairs_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2
                               ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p, defer=defer)
 
 
-def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2, symmetric=False):
     """Keep rule -> :class:`BlockRanges` without materialising the mask (``glhip_block_ranges``; interval buffers sized from its
     counting pass once the worst case would be large).  ``kind``: "dual_slack"
     (f_i + g_j > C_ij - thr, sinkhorn_samples.py:512-514) or "within" (|c_i - c_j|^2 <= thr, kernel_samples.py:244-252)."""
@@ -196,4 +196,4 @@ def block_ranges_device(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p
     code = {"dual_slack": hip.KEEP_DUAL_SLACK, "within": hip.KEEP_WITHIN}[kind]
     f32 = lambda t: None if t is None else t.detach().float().contiguous().view(-1)  # noqa: E731
     return hip.block_ranges_raw(code, rows.detach().float().contiguous(), cols.detach().float().contiguous(), f32(f), f32(g),
-                                ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p)
+                                ranges_rows.int().contiguous(), ranges_cols.int().contiguous(), thr, p, symmetric=symmetric)

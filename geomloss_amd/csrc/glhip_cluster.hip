@@ -670,11 +670,15 @@ int glhip_block_ranges_count(int kind, const float* rows, const float* cols, con
 int glhip_block_ranges(int kind, const float* rows, const float* cols, const float* f, const float* g, int Cr, int Cc, int D, int p,
                        float thr, const int32_t* ranges_rows, const int32_t* ranges_cols, int32_t* slices_rows, int32_t* red_cols,
                        int32_t* slices_cols, int32_t* red_rows, long long capacity, int32_t* status, void* stream) {
-    const int rc = check_block_ranges("glhip_block_ranges", kind, rows, cols, f, g, Cr, Cc, D, p, ranges_rows, ranges_cols, slices_rows, slices_cols);
+    // slices_cols == red_rows == NULL: the row-major pattern only (a caller whose pattern is symmetric — the debiasing terms of a
+    // Sinkhorn divergence: rows = cols, f = g — uses it for both orientations: two launches of the rule and one scan less)
+    const bool both = slices_cols != nullptr || red_rows != nullptr;
+    const int rc = check_block_ranges("glhip_block_ranges", kind, rows, cols, f, g, Cr, Cc, D, p, ranges_rows, ranges_cols, slices_rows,
+                                      both ? slices_cols : slices_rows);
     if (rc) return rc;
     if (capacity < 0) return fail(GLHIP_EINVAL, "glhip_block_ranges: capacity < 0");
     if (Cr == 0 || Cc == 0) return GLHIP_OK;
-    if (!red_cols || !red_rows || !status) return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
+    if (!red_cols || (both && !red_rows) || !status) return fail(GLHIP_EINVAL, "glhip_block_ranges: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, status, 1, 0);
     const KeepRule fwd{kind, rows, cols, f, g, D, p, thr}, bwd{kind, cols, rows, g, f, D, p, thr};
@@ -682,9 +686,11 @@ int glhip_block_ranges(int kind, const float* rows, const float* cols, const flo
     hipLaunchKernelGGL((runs_kernel<false>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, slices_rows, nullptr, nullptr, 0LL, status);
     hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_rows, Cr, slices_rows);
     hipLaunchKernelGGL((runs_kernel<true>), dim3((Cr + 3) / 4), dim3(256), 0, st, fwd, Cr, Cc, ranges_cols, nullptr, slices_rows, red_cols, capacity, status);
-    hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0LL, status);
-    hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
-    hipLaunchKernelGGL((runs_kernel<true>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, nullptr, slices_cols, red_rows, capacity, status);
+    if (both) {
+        hipLaunchKernelGGL((runs_kernel<false>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, slices_cols, nullptr, nullptr, 0LL, status);
+        hipLaunchKernelGGL(slices_kernel, dim3(1), dim3(1024), 0, st, slices_cols, Cc, slices_cols);
+        hipLaunchKernelGGL((runs_kernel<true>), dim3((Cc + 3) / 4), dim3(256), 0, st, bwd, Cc, Cr, ranges_rows, nullptr, slices_cols, red_rows, capacity, status);
+    }
     return check_launch("glhip_block_ranges");
 }
 

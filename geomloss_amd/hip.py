@@ -493,7 +493,7 @@ def _worst_case_intervals(dev):
     return _RANGES_WORST_CASE_MAX
 
 
-def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2):
+def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2, symmetric=False):
     """Keep rule on cluster pairs -> :class:`BlockRanges` (``glhip_block_ranges``).
 
     The interval buffers are sized for the worst case (every other cluster kept: Cr * ceil(Cc / 2)) while that is small —
@@ -505,14 +505,17 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
     dev = rows.device
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     with torch.cuda.device(dev):
+        # symmetric (rows is cols, f is g: the caller's word): the transposed pattern is the same arrays — one orientation is built
+        symmetric = bool(symmetric) and Cr == Cc
         slices_r = torch.empty(Cr, dtype=torch.int32, device=dev)
-        slices_c = torch.empty(Cc, dtype=torch.int32, device=dev)
+        slices_c = None if symmetric else torch.empty(Cc, dtype=torch.int32, device=dev)
         head = (int(kind), rows.data_ptr(), cols.data_ptr(), ptr(f), ptr(g), Cr, Cc, D, int(p), float(thr),
                 ranges_rows.data_ptr(), ranges_cols.data_ptr())
         cap = max(Cr * ((Cc + 1) // 2), Cc * ((Cr + 1) // 2), 1)
         if cap > _worst_case_intervals(dev):
             totals = torch.empty(2, dtype=torch.int32, device=dev)
-            _check(lib.glhip_block_ranges_count(*head, slices_r.data_ptr(), slices_c.data_ptr(), totals.data_ptr(), _stream(rows)), lib)
+            _check(lib.glhip_block_ranges_count(*head, slices_r.data_ptr(), (slices_r if symmetric else slices_c).data_ptr(), totals.data_ptr(),
+                                                _stream(rows)), lib)
             counts = [int(v) for v in totals.tolist()]                   # the one host round trip of the big case
             if min(counts) < 0:      # int32 totals: a kept pattern of >= 2^31 intervals wraps around
                 raise ValueError("geomloss_amd: the block-sparse pattern has more than 2^31 column intervals; use a larger cluster_scale.")
@@ -521,15 +524,17 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2)
         else:
             counted = False
         red_c = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-        red_r = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        red_r = None if symmetric else torch.empty((cap, 2), dtype=torch.int32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)          # set by the kernel if an interval did not fit `cap`
-        rc = lib.glhip_block_ranges(*head, slices_r.data_ptr(), red_c.data_ptr(), slices_c.data_ptr(), red_r.data_ptr(), cap,
+        rc = lib.glhip_block_ranges(*head, slices_r.data_ptr(), red_c.data_ptr(), ptr(slices_c), ptr(red_r), cap,
                                     status.data_ptr(), _stream(rows))
     _check(rc, lib)
     # worst-case buffers cannot overflow; counted ones could only if the two passes disagreed: the host is already in step with
     # the stream there (it read the totals), so the check costs one more small read-back and nothing is dropped silently
     if counted and int(status.item()) != 0:
         raise RuntimeError("geomloss_amd: glhip_block_ranges wrote more intervals than its counting pass announced.")
+    if symmetric:
+        return BlockRanges(ranges_rows, slices_r, red_c, ranges_rows, slices_r, red_c)
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
 
 

@@ -472,7 +472,9 @@ def kernel_truncation(C_xy, C_yx, C_xy_, C_yx_, f_ba, g_ab, eps, truncate=None, 
         rule = ("dual_slack", x, y, f_ba, g_ab, ranges_x, ranges_y, truncate * eps)
         dense, small_x, small_y = _goes_dense(truncate, eps, eps_last, x_.shape[0], y_.shape[0], x.shape[0], y.shape[0],
                                               (lambda: kept) if kept is not None else (lambda: kept_pairs_device(*rule, p=native_p)))
-        ranges_xy_ = None if dense else block_ranges_device(*rule, p=native_p)
+        # the debiasing terms hand in one cloud and one potential twice (sinkhorn_divergence.py:284-289): a symmetric pattern
+        symmetric = C_xy is C_yx and f_ba is g_ab
+        ranges_xy_ = None if dense else block_ranges_device(*rule, p=native_p, symmetric=symmetric)
         if ranges_xy_ is not None:
             ranges_xy_.small_i, ranges_xy_.small_j = small_x, small_y
         if verbose:     # the printed statistic only: the ranges above are the ones a silent run builds (same kernels either way)

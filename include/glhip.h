@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 116 /* 0.1.16 */
+#define GLHIP_VERSION 117 /* 0.1.17 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -386,6 +386,8 @@ int glhip_max_lines_fwd(const float* g, float* out, long R, int N, float step, i
  *   capacity: intervals each `red_*` array can hold (64-bit); Cr * ((Cc + 1) / 2) (resp. Cc * ((Cr + 1) / 2)) always suffices,
  *             glhip_block_ranges_count gives the exact number.
  *   status (1) int32 out: != 0 if capacity was exceeded (intervals beyond it are dropped, never written out of bounds).
+ *   slices_cols == red_rows == NULL (since version 117): the row-major pattern only — for symmetric patterns (rows = cols, f = g: the
+ *   debiasing terms C_xx, C_yy of sinkhorn_divergence.py:284-289), whose transposed pattern is the same arrays.
  */
 #define GLHIP_KEEP_DUAL_SLACK 0
 #define GLHIP_KEEP_WITHIN 1

@@ -146,6 +146,30 @@ def test_block_ranges_match_from_matrix(cuda, kind, Ci, Cj, exact, monkeypatch):
         assert torch.equal(rg.redranges_j[:n], ref.redranges_j) and torch.equal(rg.redranges_i[:nt], ref.redranges_i)
 
 
+@pytest.mark.parametrize("C,exact", [(300, False), (2197, False), (900, True)])
+def test_symmetric_patterns_build_one_orientation(cuda, C, exact, monkeypatch):
+    """The debiasing terms of a Sinkhorn divergence apply the keep rule to (x, x) with one potential (sinkhorn_divergence.py:284-289):
+    ``glhip_block_ranges`` with slices_cols = red_rows = NULL builds the row-major pattern only and the host uses it for both
+    orientations.  Same CSR arrays as the two-orientation call, interval for interval, and the same mask as ``from_matrix``."""
+    if exact:
+        monkeypatch.setattr(hip, "_RANGES_WORST_CASE_MAX", 0)
+    g = torch.Generator().manual_seed(C)
+    xc = torch.rand(C, 3, generator=g).to(cuda)
+    f = (torch.randn(C, generator=g) * 0.05).to(cuda)
+    sizes = torch.randint(1, 9, (C,), generator=g)
+    start = torch.cumsum(sizes, 0) - sizes
+    ri = torch.stack((start, start + sizes), 1).int().to(cuda)
+    thr = 5 * 0.01
+    both = cluster.block_ranges_device("dual_slack", xc, xc, f, f, ri, ri, thr, p=2)
+    one = cluster.block_ranges_device("dual_slack", xc, xc, f, f, ri, ri, thr, p=2, symmetric=True)
+    n = int(both.slices_i[-1])
+    assert torch.equal(one.slices_i, both.slices_i) and torch.equal(one.redranges_j[:n], both.redranges_j[:n])
+    assert torch.equal(one.slices_j, both.slices_j) and torch.equal(one.redranges_i[:n], both.redranges_i[:n])      # the pattern IS symmetric
+    assert one.slices_j is one.slices_i and one.redranges_i is one.redranges_j
+    m = _mask_of(one, C, C)
+    assert (m == m.T).all() and (_mask_of(one.t(), C, C) == m).all()
+
+
 def test_multiscale_losses_are_the_same_on_both_clustering_paths(cuda, monkeypatch):
     """End to end: device clustering + device keep rule vs the torch helpers (forced by disabling the fast path)."""
     g = torch.Generator().manual_seed(5)
@@ -158,6 +182,7 @@ def test_multiscale_losses_are_the_same_on_both_clustering_paths(cuda, monkeypat
             import geomloss_amd.sinkhorn_samples as ss
             monkeypatch.setattr(ks, "native_clustering_applies", lambda *a, **k: False)
             monkeypatch.setattr(ss, "native_clustering_applies", lambda *a, **k: False)
+            monkeypatch.setattr(ss, "native_keep_rule_applies", lambda *a, **k: False)      # (the keep rule has its own predicate since round 6)
         xg = x.clone().requires_grad_(True)
         Ls = SamplesLoss("sinkhorn", p=2, blur=0.05, scaling=0.7, backend="multiscale")(xg, y)
         (gs,) = torch.autograd.grad(Ls, [xg])
