@@ -205,6 +205,61 @@ int main(void) {
         free(xb); free(yb); free(hb); free(vb); free(o1); free(o2); free(yq); free(hq); free(vq);
     }
 
+    /* 5c. the fused half-step in double precision (glhip_sinkhorn_step_f64, round 6): out = (prev + damping * softmin(logw + pot / eps)) / 2 */
+    {
+        static double potd[M], prevd[N], hh[M], want[N], got64[N];
+        for (int k = 0; k < M; ++k) { potd[k] = 0.05 * normal(); hh[k] = hd[k] + potd[k] / (double)eps; }
+        for (int k = 0; k < N; ++k) prevd[k] = normal();
+        double *X = to_device(xd, sizeof xd), *Y = to_device(yd, sizeof yd), *H = to_device(hd, sizeof hd);
+        double *P = to_device(potd, sizeof potd), *V = to_device(prevd, sizeof prevd), *O = to_device(NULL, sizeof got64);
+        GL_OK(glhip_sinkhorn_step_f64(X, Y, H, P, V, O, 1, N, M, D, (double)eps, 0.8, 2, NULL, NULL, NULL, 0, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpy(got64, O, sizeof got64, hipMemcpyDeviceToHost));
+        oracle_softmin(xd, yd, hh, want, N, M, D, (double)eps, 2, NULL, NULL, NULL, 0);
+        double worst = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double w = 0.5 * (prevd[i] + 0.8 * want[i]);
+            if (fabs(got64[i] - w) > worst) worst = fabs(got64[i] - w);
+        }
+        report("glhip_sinkhorn_step_f64 (double precision half-step)", worst, 1e-12);
+        HIP_OK(hipFree(X)); HIP_OK(hipFree(Y)); HIP_OK(hipFree(H)); HIP_OK(hipFree(P)); HIP_OK(hipFree(V)); HIP_OK(hipFree(O));
+    }
+
+    /* 5d. block-sparse ranges from a keep rule on cluster pairs (glhip_block_ranges, sinkhorn_samples.py:512-530): a symmetric pattern
+     *     (rows = cols, f = g) built in one orientation only (slices_cols = red_rows = NULL, version 117) = the two-orientation call */
+    {
+        enum { C = 64 };
+        static float cf[C * D], ff[C];
+        static int32_t rr[C * 2];
+        for (int k = 0; k < C * D; ++k) cf[k] = (float)uniform();
+        for (int k = 0; k < C; ++k) { ff[k] = (float)(0.02 * normal()); rr[2 * k] = 10 * k; rr[2 * k + 1] = 10 * k + 7 + k % 3; }
+        float *cc = to_device(cf, sizeof cf), *fd = to_device(ff, sizeof ff);
+        int32_t* rd = to_device(rr, sizeof rr);
+        const long long cap = (long long)C * ((C + 1) / 2);
+        int32_t *s1 = to_device(NULL, C * 4), *r1 = to_device(NULL, (size_t)cap * 8), *s2 = to_device(NULL, C * 4), *r2 = to_device(NULL, (size_t)cap * 8);
+        int32_t *s3 = to_device(NULL, C * 4), *r3 = to_device(NULL, (size_t)cap * 8), *st = to_device(NULL, 4);
+        GL_OK(glhip_block_ranges(GLHIP_KEEP_DUAL_SLACK, cc, cc, fd, fd, C, C, D, 2, 0.05f, rd, rd, s1, r1, s2, r2, cap, st, stream));
+        GL_OK(glhip_block_ranges(GLHIP_KEEP_DUAL_SLACK, cc, cc, fd, fd, C, C, D, 2, 0.05f, rd, rd, s3, r3, NULL, NULL, cap, st, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        static int32_t a1[C], a2[C], a3[C];
+        HIP_OK(hipMemcpy(a1, s1, sizeof a1, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(a2, s2, sizeof a2, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(a3, s3, sizeof a3, hipMemcpyDeviceToHost));
+        int bad = a1[C - 1] <= 0;      /* something is kept (the diagonal at least) */
+        for (int k = 0; k < C; ++k) bad |= (a1[k] != a2[k]) | (a1[k] != a3[k]);
+        const size_t nint = (size_t)a1[C - 1];
+        int32_t *b1 = malloc(nint * 8), *b2 = malloc(nint * 8), *b3 = malloc(nint * 8);
+        HIP_OK(hipMemcpy(b1, r1, nint * 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(b2, r2, nint * 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(b3, r3, nint * 8, hipMemcpyDeviceToHost));
+        bad |= memcmp(b1, b2, nint * 8) != 0 || memcmp(b1, b3, nint * 8) != 0;
+        printf("glhip_block_ranges: %zu intervals for %d x %d clusters\n", nint, C, C);
+        report("glhip_block_ranges: symmetric pattern, one orientation = both orientations", bad ? 1.0 : 0.0, 0.5);
+        free(b1); free(b2); free(b3);
+        HIP_OK(hipFree(cc)); HIP_OK(hipFree(fd)); HIP_OK(hipFree(rd)); HIP_OK(hipFree(s1)); HIP_OK(hipFree(r1)); HIP_OK(hipFree(s2));
+        HIP_OK(hipFree(r2)); HIP_OK(hipFree(s3)); HIP_OK(hipFree(r3)); HIP_OK(hipFree(st));
+    }
+
     /* 6. error paths: code + thread-local message, nothing thrown across the ABI */
     {
         int rc = glhip_softmin_fwd(x, y, h, out, 1, N, M, D, eps, 3, GLHIP_F32, NULL, NULL, NULL, 0, ws, ws_bytes, 0, stream);
