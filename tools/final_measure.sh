@@ -34,6 +34,7 @@ leg() {   # leg <name> <output file | -> <timeout s> <command...>     (SKIP="nam
 leg bench gpurun_out/bench_$TAG.json 900 python bench.py --steps 20 --warmup 5
 leg profile_gpu - 900 bash tools/profile_gpu.sh $TAG                    # kernel trace + PMC passes of the headline command
 leg summarize_profile - 200 python tools/summarize_profile.py gpurun_out/prof_$TAG $TAG
+cp profiles/${TAG}_kernel_trace_stats.txt profiles/${TAG}_pmc_softmin.json gpurun_out/ 2>/dev/null      # (written under profiles/ on the box: only gpurun_out/ comes back)
 leg profile_kernels - 900 bash tools/profile_kernels.sh $TAG            # kernel trace + PMC of every reduction at 1e6
 leg trace_all - 900 bash tools/trace_all.sh                             # per-config kernel traces
 leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_report.py
