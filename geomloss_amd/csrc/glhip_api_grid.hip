@@ -2,7 +2,91 @@
 #include "glhip_launch.h"
 #include "glhip_lines.h"
 
+namespace {
+
+// ---- the elementwise front and back end of a Sinkhorn loss on a few thousand points (round 6): such a loss is bound by the host's
+// launch rate (26 launches, 0.39 ms at N = 2000, of which the soft-mins are 9 launches and 0.16 ms), so the three multi-tensor
+// launches of `log_weights` and the seven of the loss formula become one kernel each.
+
+struct LogWeightsArgs {
+    const float* w[4];
+    float* out[4];
+    long n[4];
+    int count;
+};
+
+// log(w) with log(0) -> -100000 (sinkhorn_divergence.py:61-65): max(log(max(w, 0)), -100000); NaN stays NaN
+__global__ void __launch_bounds__(256) log_weights_kernel(LogWeightsArgs a) {
+    const int k = blockIdx.y;
+    if (k >= a.count) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n[k]; i += (long)gridDim.x * 256) {
+        const float w = a.w[k][i];
+        const float l = logf(w > 0.f ? w : (w == w ? 0.f : w));      // (w <= 0 -> log 0 = -inf; NaN propagates)
+        a.out[k][i] = (l == l) ? fmaxf(l, -100000.0f) : l;
+    }
+}
+
+// out[b] = sum_i a_i (f_ba_i - f_aa_i) + sum_j b_j (g_ab_j - g_bb_j), accumulated in float64 in a fixed order (one workgroup per
+// batch item, thread t takes elements t, t + 1024, ...; butterfly + LDS): sinkhorn_cost, balanced case, sinkhorn_divergence.py:171-199
+__global__ void __launch_bounds__(1024) sinkhorn_cost_kernel(const float* __restrict__ a, const float* __restrict__ f_ba,
+                                                             const float* __restrict__ f_aa, const float* __restrict__ b,
+                                                             const float* __restrict__ g_ab, const float* __restrict__ g_bb,
+                                                             float* __restrict__ out, int N, int M, long a_stride, long b_stride) {
+    __shared__ double part[16];
+    const int bi = blockIdx.x, tid = threadIdx.x;
+    const float* ab = a + (long)bi * a_stride;      // stride 0: one weight vector shared by the batch
+    const float* bb = b + (long)bi * b_stride;
+    double acc = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const long k = (long)bi * N + i;
+        acc += (double)ab[i] * ((double)f_ba[k] - (f_aa ? (double)f_aa[k] : 0.0));
+    }
+    for (int j = tid; j < M; j += 1024) {
+        const long k = (long)bi * M + j;
+        acc += (double)bb[j] * ((double)g_ab[k] - (g_bb ? (double)g_bb[k] : 0.0));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += part[w];
+        out[bi] = (float)tot;
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+int glhip_log_weights(const float* const* w, float* const* out, const long* n, int count, void* stream) {
+    if (count < 0 || count > 4) return fail(GLHIP_EINVAL, "glhip_log_weights: count must be 0 ... 4 (got %d)", count);
+    if (count == 0) return GLHIP_OK;
+    if (!w || !out || !n) return fail(GLHIP_EINVAL, "glhip_log_weights: NULL pointer");
+    LogWeightsArgs a{};
+    long nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        if (n[k] < 0 || (n[k] > 0 && (!w[k] || !out[k]))) return fail(GLHIP_EINVAL, "glhip_log_weights: bad vector %d", k);
+        a.w[k] = w[k]; a.out[k] = out[k]; a.n[k] = n[k];
+        nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    a.count = count;
+    if (nmax == 0) return GLHIP_OK;
+    const long blocks = (nmax + 255) / 256;
+    hipLaunchKernelGGL(log_weights_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), count, 1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("glhip_log_weights");
+}
+
+int glhip_sinkhorn_cost(const float* a, const float* f_ba, const float* f_aa, const float* b, const float* g_ab, const float* g_bb,
+                        float* out, int B, int N, int M, int a_batched, int b_batched, void* stream) {
+    if (B < 0 || N < 0 || M < 0) return fail(GLHIP_EINVAL, "glhip_sinkhorn_cost: bad sizes");
+    if (B == 0) return GLHIP_OK;
+    if (!out || (N > 0 && (!a || !f_ba)) || (M > 0 && (!b || !g_ab))) return fail(GLHIP_EINVAL, "glhip_sinkhorn_cost: NULL pointer");
+    if ((f_aa == nullptr) != (g_bb == nullptr)) return fail(GLHIP_EINVAL, "glhip_sinkhorn_cost: f_aa and g_bb are given together (debiasing) or not at all");
+    hipLaunchKernelGGL(sinkhorn_cost_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), a, f_ba, f_aa, b, g_ab, g_bb, out, N, M,
+                       a_batched ? (long)N : 0L, b_batched ? (long)M : 0L);
+    return check_launch("glhip_sinkhorn_cost");
+}
 
 static int lines_check(const char* fn, const void* a, const void* b, long R, int N, float eps, int p) {
     if (R < 0 || N < 0) return fail(GLHIP_EINVAL, "%s: negative size (R=%ld, N=%d)", fn, R, N);

@@ -54,6 +54,8 @@ SIGNATURES = {
     "glhip_kernel_conv_fwd_grad": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                             _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
+    "glhip_log_weights": (_c_int, [_vp, _vp, _vp, _c_int, _vp]),
+    "glhip_sinkhorn_cost": (_c_int, [_vp] * 7 + [_c_int] * 5 + [_vp]),
     "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_lse_lines_bwd": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
     "glhip_cmin_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int] + _RANGES + _TAIL),
@@ -536,6 +538,78 @@ def block_ranges_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2,
     if symmetric:
         return BlockRanges(ranges_rows, slices_r, red_c, ranges_rows, slices_r, red_c)
     return BlockRanges(ranges_rows, slices_r, red_c, ranges_cols, slices_c, red_r)
+
+
+# ----------------------------------------------------------------------------------------------
+#  the elementwise front and back end of a small Sinkhorn loss as one launch each (glhip_log_weights, glhip_sinkhorn_cost)
+# ----------------------------------------------------------------------------------------------
+
+_SMALL_ENDS_MAX = 32768      # points per measure up to which the one-workgroup-per-item cost kernel beats torch's tree of reductions
+
+
+def small_ends_apply(*tensors):
+    """fp32 CUDA vectors of at most _SMALL_ENDS_MAX entries per batch item, library present: the regime where a loss is bound by the
+    host's launch rate (a 2000-point loss: 26 launches, 9 of them soft-mins)."""
+    return (library_available() and all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.shape[-1] <= _SMALL_ENDS_MAX)
+                                        for t in tensors))
+
+
+def log_weights_raw(ws):
+    """[log(w) with log(0) -> -100000 for w in ws] (up to 4 fp32 CUDA vectors of any shape) in ONE launch."""
+    lib = load_library()
+    ws = [w.detach().contiguous() for w in ws]
+    outs = [torch.empty_like(w) for w in ws]
+    k = len(ws)
+    arr_w = (ctypes.c_void_p * k)(*[w.data_ptr() for w in ws])
+    arr_o = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+    arr_n = (ctypes.c_long * k)(*[w.numel() for w in ws])
+    with torch.cuda.device(ws[0].device):
+        _check(lib.glhip_log_weights(arr_w, arr_o, arr_n, k, _stream(ws[0])), lib)
+    return outs
+
+
+def _cost_raw(a, f_ba, f_aa, b, g_ab, g_bb, B, N, M):
+    lib = load_library()
+    c = lambda t: None if t is None else t.detach().contiguous()  # noqa: E731
+    a, f_ba, f_aa, b, g_ab, g_bb = (c(t) for t in (a, f_ba, f_aa, b, g_ab, g_bb))
+    out = torch.empty(B, dtype=torch.float32, device=f_ba.device)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(f_ba.device):
+        _check(lib.glhip_sinkhorn_cost(ptr(a), ptr(f_ba), ptr(f_aa), ptr(b), ptr(g_ab), ptr(g_bb), out.data_ptr(), B, N, M,
+                                       int(a.numel() == B * N), int(b.numel() == B * M), _stream(f_ba)), lib)
+    return out
+
+
+class _SinkhornCost(torch.autograd.Function):
+    """<a, f_ba - f_aa> + <b, g_ab - g_bb> per batch item as one launch (``sinkhorn_cost``, balanced; f_aa = g_bb = None: no
+    debiasing).  The backward pass is written with differentiable torch operations of the inputs — the loss formula is bilinear —
+    so that gradients of any order flow as they do through the seven torch operations it replaces."""
+
+    @staticmethod
+    def forward(ctx, batch, a, f_ba, f_aa, b, g_ab, g_bb):
+        B = f_ba.shape[0] if batch else 1
+        N, M = f_ba.shape[-1], g_ab.shape[-1]
+        ctx.batch = batch
+        ctx.save_for_backward(a, f_ba, f_aa, b, g_ab, g_bb)
+        out = _cost_raw(a, f_ba, f_aa, b, g_ab, g_bb, B, N, M)
+        return out if batch else out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, f_ba, f_aa, b, g_ab, g_bb = ctx.saved_tensors
+        gg = g.reshape(-1, 1) if ctx.batch else g
+        need = ctx.needs_input_grad
+        like = lambda v, t: v.reshape(t.shape) if v.numel() == t.numel() else v.sum(0).reshape(t.shape)  # noqa: E731  (weights shared by the batch)
+        ga = like(gg * (f_ba - f_aa if f_aa is not None else f_ba), a) if need[1] else None
+        gb = like(gg * (g_ab - g_bb if g_bb is not None else g_ab), b) if need[4] else None
+        wa = (gg * a).expand_as(f_ba) if (need[2] or need[3]) else None
+        wb = (gg * b).expand_as(g_ab) if (need[5] or need[6]) else None
+        return (None, ga, wa if need[2] else None, (-wa if (need[3] and f_aa is not None) else None), gb, wb if need[5] else None,
+                (-wb if (need[6] and g_bb is not None) else None))
+
+
+def sinkhorn_cost_fused(a, f_ba, f_aa, b, g_ab, g_bb, batch):
+    return _SinkhornCost.apply(bool(batch), a, f_ba, f_aa, b, g_ab, g_bb)
 
 
 def kept_pairs_raw(kind, rows, cols, f, g, ranges_rows, ranges_cols, thr, p=2, defer=False):

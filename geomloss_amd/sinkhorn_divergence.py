@@ -34,6 +34,24 @@ def dampening(eps, rho):
     return 1 if rho is None else 1 / (1 + eps / rho)
 
 
+def _hip():
+    from . import hip      # (imported on first use: the dense CPU paths of this module never touch the library)
+    return hip
+
+
+def _fused_cost_applies(a, b, f_aa, g_bb, g_ab, f_ba, batch):
+    """fp32 CUDA potentials and weights of matching shapes, at most 32768 points per measure: (B,N) / (B,M) with ``batch``, vectors without."""
+    ts = (a, b, f_aa, g_bb, g_ab, f_ba)
+    if not all(t is None or (torch.is_tensor(t) and t.is_cuda) for t in ts) or not _hip().small_ends_apply(*ts):
+        return False
+    if f_ba.dim() != (2 if batch else 1) or g_ab.dim() != f_ba.dim() or (batch and g_ab.shape[0] != f_ba.shape[0]):
+        return False
+    B = f_ba.shape[0] if batch else 1
+    ok = lambda w, f: w.numel() in (f.shape[-1], B * f.shape[-1]) and w.shape[-1] == f.shape[-1]  # noqa: E731
+    same = lambda u, f: u is None or u.shape == f.shape  # noqa: E731
+    return ok(a, f_ba) and ok(b, g_ab) and same(f_aa, f_ba) and same(g_bb, g_ab) and B <= 65535
+
+
 def log_weights(a):
     """log(a), with log(0) replaced by -100000 (``:61-65``)."""
     # clamps instead of the reference's masked assignment: same values, but no boolean-mask indexing (which goes
@@ -47,6 +65,8 @@ def log_weights_many(weights):
     """:func:`log_weights` of several measures, detached (every use of a log-weight vector in the loop is), with three multi-tensor
     launches for the lot where torch offers them (the 4 vectors of a two-scale loss: 3 launches instead of 12)."""
     ws = [w.detach() for w in weights]
+    if 1 <= len(ws) <= 4 and _hip().small_ends_apply(*ws):      # a loss on a few thousand points: one launch (glhip_log_weights)
+        return _hip().log_weights_raw(ws)
     if len(ws) > 1 and all(w.is_cuda for w in ws) and hasattr(torch, "_foreach_clamp_min_") and hasattr(torch, "_foreach_log_"):
         out = torch._foreach_clamp_min(ws, 0)
         torch._foreach_log_(out)
@@ -118,6 +138,9 @@ def sinkhorn_cost(eps, rho, a, b, f_aa, g_bb, g_ab, f_ba, batch=False, debias=Tr
         return (f_ba - f_aa, g_ab - g_bb) if debias else (f_ba, g_ab)
 
     if rho is None:  # balanced
+        if _fused_cost_applies(a, b, f_aa if debias else None, g_bb if debias else None, g_ab, f_ba, batch):
+            # a loss on a few thousand points is bound by the launch rate: the seven elementwise launches below as one (glhip_sinkhorn_cost)
+            return _hip().sinkhorn_cost_fused(a, f_ba, f_aa if debias else None, b, g_ab, g_bb if debias else None, batch)
         if debias:
             return scal_sum(a, f_ba - f_aa, b, g_ab - g_bb, batch=batch)
         return scal_sum(a, f_ba, b, g_ab, batch=batch)

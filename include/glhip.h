@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 117 /* 0.1.17 */
+#define GLHIP_VERSION 118 /* 0.1.18 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -231,6 +231,20 @@ int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, co
                                 float* f_ba_out, float* g_ab_out, float* f_aa_out, float* g_bb_out,
                                 int B, int N, int M, int Nc, int Mc, int D, float eps, float damping, int p, int in_dtype,
                                 void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * The elementwise front and back end of a Sinkhorn loss, for problems of a few thousand points whose time is the host's launch rate
+ * (round 6; a 2000-point loss is 26 launches of which the soft-mins are 9):
+ *   glhip_log_weights: out_k[i] = log(w_k[i]) with log(0) -> -100000 for up to 4 vectors in ONE launch — `log_weights`
+ *     (sinkhorn_divergence.py:61-65; NaN weights stay NaN).  w, out, n: HOST arrays of `count` device pointers / lengths.
+ *   glhip_sinkhorn_cost: out[b] = <a_b, f_ba_b - f_aa_b> + <b_b, g_ab_b - g_bb_b> — `sinkhorn_cost`, balanced case
+ *     (sinkhorn_divergence.py:171-199) — accumulated in float64 in a fixed order; f_aa = g_bb = NULL: without debiasing.
+ *     f_*, (B,N) and g_*, (B,M) fp32; a (B,N) if a_batched else (N) shared by the batch, b likewise; out (B) fp32.  One workgroup per
+ *     batch item: meant for N, M up to a few 1e4 (beyond, a tree of torch reductions is faster).
+ */
+int glhip_log_weights(const float* const* w, float* const* out, const long* n, int count, void* stream);
+int glhip_sinkhorn_cost(const float* a, const float* f_ba, const float* f_aa, const float* b, const float* g_ab, const float* g_bb,
+                        float* out, int B, int N, int M, int a_batched, int b_batched, void* stream);
 
 /*
  * Log-sum-exp along the lines of a regular grid — the separable soft-min of the reference's image / volume path

@@ -257,6 +257,55 @@ def test_block_sparse_leftover_row_tiles_are_carried(cuda):
                 assert err.max() < 2e-6 + 3e-6 * np.abs(ref).max(), (flags, density, int(err.argmax()))
 
 
+def test_fused_ends_of_a_small_loss(cuda):
+    """``glhip_log_weights`` and ``glhip_sinkhorn_cost`` (round 6): the three multi-tensor launches of ``log_weights`` and the seven
+    elementwise launches of the balanced loss formula (sinkhorn_divergence.py:61-65,171-199) as one kernel each.  Values against the
+    torch expressions they replace; first and second derivatives of the cost through autograd (the formula is bilinear: the backward
+    pass is differentiable torch code); shared and per-item weights, with and without debiasing, batched and not."""
+    import geomloss_amd.sinkhorn_divergence as sd
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.rand(n, generator=g).to(cuda) for n in (700, 1, 4097)] + [torch.rand(3, 50, generator=g).to(cuda)]
+    ws[0][::7] = 0.0
+    ws[0][3] = -1.0
+    ws[2][5] = float("nan")
+    got = hip.log_weights_raw(ws)
+    for w, l in zip(ws, got):
+        want = w.clamp_min(0).log().clamp_min(-100000.0)
+        assert l.shape == w.shape and torch.equal(torch.isnan(l), torch.isnan(want))
+        assert torch.equal(torch.nan_to_num(l, nan=0.0), torch.nan_to_num(want, nan=0.0)) or (torch.nan_to_num(l) - torch.nan_to_num(want)).abs().max() < 1e-6
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(sd.log_weights_many(ws[:2]), got[:2]))      # the hook takes the fused path
+
+    for batch, debias, shared in ((True, True, False), (True, False, False), (False, True, False), (True, True, True)):
+        B, N, M = (4, 300, 450) if batch else (1, 300, 450)
+        shp = (lambda n: (B, n)) if batch else (lambda n: (n,))
+        mk = lambda s_: (torch.randn(s_, generator=g).to(cuda) * 0.1).requires_grad_(True)  # noqa: E731
+        f_ba, f_aa, g_ab, g_bb = mk(shp(N)), mk(shp(N)), mk(shp(M)), mk(shp(M))
+        a = (torch.rand((N,) if shared else shp(N), generator=g).to(cuda) / N).requires_grad_(True)
+        b = (torch.rand((M,) if shared else shp(M), generator=g).to(cuda) / M).requires_grad_(True)
+        fused = hip.sinkhorn_cost_fused(a, f_ba, f_aa if debias else None, b, g_ab, g_bb if debias else None, batch)
+        dd = lambda t: t.double()  # noqa: E731
+        fa = dd(f_ba) - dd(f_aa) if debias else dd(f_ba)
+        gb = dd(g_ab) - dd(g_bb) if debias else dd(g_ab)
+        want = (dd(a) * fa).sum(-1) + (dd(b) * gb).sum(-1)
+        assert fused.shape == want.shape and relerr(fused.detach().cpu().numpy(), want.detach().cpu().numpy()) < 2e-7
+        ins = [a, f_ba, b, g_ab] + ([f_aa, g_bb] if debias else [])
+        v = torch.randn(want.shape, generator=g).to(cuda)
+        g1 = torch.autograd.grad((fused * v).sum(), ins, create_graph=True)
+        g2 = torch.autograd.grad((want * v.double()).sum(), ins, create_graph=True)
+        for u, w_ in zip(g1, g2):
+            assert u.shape == w_.shape and relerr(u.detach().cpu().numpy(), w_.detach().cpu().numpy()) < 1e-6
+        # second order: d/df_ba of <grad_a, r> — the mixed derivative a bilinear form has
+        r = torch.randn(a.shape, generator=g).to(cuda)
+        h1, = torch.autograd.grad((g1[0] * r).sum(), [f_ba])
+        h2, = torch.autograd.grad((g2[0] * r.double()).sum(), [f_ba])
+        assert relerr(h1.cpu().numpy(), h2.cpu().numpy()) < 1e-6
+    # the hook of the loss formula
+    f_ba, f_aa, g_ab, g_bb = (torch.randn(2, 64, generator=g).to(cuda) for _ in range(4))
+    a = b = torch.full((2, 64), 1 / 64, device=cuda)
+    out = sd.sinkhorn_cost(0.01, None, a, b, f_aa, g_bb, g_ab, f_ba, batch=True, debias=True)
+    assert relerr(out.cpu().numpy(), ((a * (f_ba - f_aa)).sum(1) + (b * (g_ab - g_bb)).sum(1)).cpu().numpy()) < 1e-6
+
+
 def test_block_sparse_very_uneven_row_blocks(cuda):
     """Row blocks of 1 ... 6000 rows (voxel clusters of a cloud sampled on a surface look like this): the launch cuts them
     into row chunks (build_row_chunks_kernel), one workgroup each.  Forward, gradient, gaussian product and gradient against
