@@ -55,9 +55,46 @@ __global__ void __launch_bounds__(1024) sinkhorn_cost_kernel(const float* __rest
     }
 }
 
+// lo_hi[d] = min, lo_hi[D + d] = max of coordinate d over the rows of x and y together: one workgroup, no atomics (exact whatever
+// the order): the front end of a loss whose `diameter` is measured (max_diameter, sinkhorn_divergence.py:96-112)
+template <typename T>
+__global__ void __launch_bounds__(1024) bounding_box_kernel(const T* __restrict__ x, long nx, const T* __restrict__ y, long ny, int D,
+                                                            float* __restrict__ lo_hi) {
+    const int tid = threadIdx.x;
+    // thread t owns coordinate t % D of the points t / D, t / D + stride, ... (stride = the points a pass of the workgroup covers)
+    const int per = 1024 / D, d = tid % D, slot = tid / D;
+    float lo = INFINITY, hi = -INFINITY;
+    bool nan = false;      // torch.aminmax propagates NaN coordinates (fminf / fmaxf drop them)
+    if (slot < per) {
+        for (long i = slot; i < nx; i += per) { const float v = to_f32<T>(x[i * D + d]); lo = fminf(lo, v); hi = fmaxf(hi, v); nan |= v != v; }
+        for (long i = slot; i < ny; i += per) { const float v = to_f32<T>(y[i * D + d]); lo = fminf(lo, v); hi = fmaxf(hi, v); nan |= v != v; }
+    }
+    if (nan) lo = hi = NAN;
+    // the per-thread extrema of a coordinate meet through LDS
+    __shared__ float all_lo[1024], all_hi[1024];
+    all_lo[tid] = lo; all_hi[tid] = hi;
+    __syncthreads();
+    if (tid < D) {
+        float a = INFINITY, b = -INFINITY;
+        bool bad = false;
+        for (int t = tid; t < per * D; t += D) { a = fminf(a, all_lo[t]); b = fmaxf(b, all_hi[t]); bad |= all_lo[t] != all_lo[t]; }
+        lo_hi[tid] = bad ? NAN : a; lo_hi[D + tid] = bad ? NAN : b;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int glhip_bounding_box(const void* x, long nx, const void* y, long ny, int D, int in_dtype, float* lo_hi, void* stream) {
+    if (nx < 0 || ny < 0 || D < 1 || D > 16) return fail(D > 16 ? GLHIP_EUNSUPPORTED : GLHIP_EINVAL, "glhip_bounding_box: bad sizes (D <= 16)");
+    if (in_dtype != GLHIP_F32 && in_dtype != GLHIP_BF16) return fail(GLHIP_EINVAL, "glhip_bounding_box: bad in_dtype %d", in_dtype);
+    if (!lo_hi || (nx > 0 && !x) || (ny > 0 && !y)) return fail(GLHIP_EINVAL, "glhip_bounding_box: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (in_dtype == GLHIP_F32) hipLaunchKernelGGL(bounding_box_kernel<float>, dim3(1), dim3(1024), 0, st, static_cast<const float*>(x), nx, static_cast<const float*>(y), ny, D, lo_hi);
+    else hipLaunchKernelGGL(bounding_box_kernel<bf16_t>, dim3(1), dim3(1024), 0, st, static_cast<const bf16_t*>(x), nx, static_cast<const bf16_t*>(y), ny, D, lo_hi);
+    return check_launch("glhip_bounding_box");
+}
 
 int glhip_log_weights(const float* const* w, float* const* out, const long* n, int count, void* stream) {
     if (count < 0 || count > 4) return fail(GLHIP_EINVAL, "glhip_log_weights: count must be 0 ... 4 (got %d)", count);

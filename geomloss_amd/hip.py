@@ -29,6 +29,7 @@ XD_MAX_DIM = 16                 # p = 2 soft-min forward / half-step and gaussia
 
 # every symbol include/glhip.h declares, with its ctypes signature
 _c_int, _c_float, _vp, _c_size = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+_c_long = ctypes.c_long
 _RANGES = [_vp, _vp, _vp, _c_int]
 _TAIL = [_vp, _c_size, _c_int, _vp]  # workspace, workspace_bytes, flags, stream
 SIGNATURES = {
@@ -54,6 +55,7 @@ SIGNATURES = {
     "glhip_kernel_conv_fwd_grad": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float,
                                             _c_int] + _RANGES + _TAIL),
     "glhip_softmin_dense_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
+    "glhip_bounding_box": (_c_int, [_vp, _c_long, _vp, _c_long, _c_int, _c_int, _vp, _vp]),
     "glhip_log_weights": (_c_int, [_vp, _vp, _vp, _c_int, _vp]),
     "glhip_sinkhorn_cost": (_c_int, [_vp] * 7 + [_c_int] * 5 + [_vp]),
     "glhip_lse_lines_fwd": (_c_int, [_vp, _vp, ctypes.c_long, _c_int, _c_float, _c_int, _vp]),
@@ -552,6 +554,26 @@ def small_ends_apply(*tensors):
     host's launch rate (a 2000-point loss: 26 launches, 9 of them soft-mins)."""
     return (library_available() and all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.shape[-1] <= _SMALL_ENDS_MAX)
                                         for t in tensors))
+
+
+_BBOX_MAX_POINTS = 16384      # one workgroup: beyond, the latency of its serial sweep exceeds the two torch reductions it replaces
+
+
+def bounding_box_applies(x, y):
+    """(n, D) contiguous fp32 / bf16 CUDA clouds of one dtype, D <= 16, at most _BBOX_MAX_POINTS points together."""
+    return (library_available() and x.is_cuda and y.is_cuda and x.device == y.device and x.dtype == y.dtype
+            and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and y.dim() == 2 and x.shape[1] == y.shape[1] <= 16
+            and x.is_contiguous() and y.is_contiguous() and 0 < x.shape[0] + y.shape[0] <= _BBOX_MAX_POINTS and _SMALL_ENDS_MAX > 0)
+
+
+def bounding_box(x, y):
+    """(mins, maxs) of the coordinates of x and y together, fp32 (D,) each: ``glhip_bounding_box``, one launch."""
+    lib = load_library()
+    D = x.shape[1]
+    out = torch.empty(2 * D, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.glhip_bounding_box(x.data_ptr(), x.shape[0], y.data_ptr(), y.shape[0], D, _dtype_code(x), out.data_ptr(), _stream(x)), lib)
+    return out[:D], out[D:]
 
 
 def log_weights_raw(ws):

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GLHIP_VERSION 118 /* 0.1.18 */
+#define GLHIP_VERSION 119 /* 0.1.19 */
 
 /* element type of the point clouds x, y */
 #define GLHIP_F32 0
@@ -241,7 +241,11 @@ int glhip_sinkhorn_extrapolate4(const void* x, const void* y, const void* xc, co
  *     (sinkhorn_divergence.py:171-199) — accumulated in float64 in a fixed order; f_aa = g_bb = NULL: without debiasing.
  *     f_*, (B,N) and g_*, (B,M) fp32; a (B,N) if a_batched else (N) shared by the batch, b likewise; out (B) fp32.  One workgroup per
  *     batch item: meant for N, M up to a few 1e4 (beyond, a tree of torch reductions is faster).
+ *   glhip_bounding_box: lo_hi (2 D) fp32 out = the D minima then the D maxima of the coordinates of x (nx, D) and y (ny, D) together
+ *     (either may be empty: +inf / -inf there) — the reductions of `max_diameter` (sinkhorn_divergence.py:96-112: cat, aminmax) in one
+ *     launch of one workgroup; exact (minima and maxima); D <= 16; meant for clouds of up to ~1e4 points (one workgroup sweeps them).
  */
+int glhip_bounding_box(const void* x, long nx, const void* y, long ny, int D, int in_dtype, float* lo_hi, void* stream);
 int glhip_log_weights(const float* const* w, float* const* out, const long* n, int count, void* stream);
 int glhip_sinkhorn_cost(const float* a, const float* f_ba, const float* f_aa, const float* b, const float* g_ab, const float* g_bb,
                         float* out, int B, int N, int M, int a_batched, int b_batched, void* stream);

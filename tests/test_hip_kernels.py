@@ -299,6 +299,19 @@ def test_fused_ends_of_a_small_loss(cuda):
         h1, = torch.autograd.grad((g1[0] * r).sum(), [f_ba])
         h2, = torch.autograd.grad((g2[0] * r.double()).sum(), [f_ba])
         assert relerr(h1.cpu().numpy(), h2.cpu().numpy()) < 1e-6
+    # glhip_bounding_box: the reductions of max_diameter in one launch — exact, NaN coordinates propagate as in torch.aminmax
+    import geomloss_amd.sinkhorn_divergence as sdv
+    for D, nx, ny, dt in ((3, 2000, 1700, torch.float32), (1, 5, 7000, torch.float32), (16, 300, 1, torch.float32), (7, 999, 1001, torch.bfloat16)):
+        xb, yb = (torch.randn(nx, D, generator=g).to(cuda).to(dt)), (torch.randn(ny, D, generator=g).to(cuda).to(dt) * 2 + 1)
+        lo, hi = hip.bounding_box(xb, yb)
+        z = torch.cat((xb, yb)).float()
+        assert torch.equal(lo, z.min(0)[0]) and torch.equal(hi, z.max(0)[0])
+        if dt == torch.float32:
+            assert hip.bounding_box_applies(xb, yb)
+            assert sdv.max_diameter(xb, yb) == (z.max(0)[0] - z.min(0)[0]).norm().item()      # the same float32 norm of the same extents
+    xb[3, 0] = float("nan")
+    lo, hi = hip.bounding_box(xb, yb)
+    assert torch.isnan(lo[0]) and torch.isnan(hi[0]) and not torch.isnan(lo[1:]).any()
     # the hook of the loss formula
     f_ba, f_aa, g_ab, g_bb = (torch.randn(2, 64, generator=g).to(cuda) for _ in range(4))
     a = b = torch.full((2, 64), 1 / 64, device=cuda)
