@@ -1036,14 +1036,15 @@ class _Last4(torch.autograd.Function):
         if k == 4:
             specs += [(x_in, plan.x, plan.a_log, pots[2]), (y_in, plan.y, plan.b_log, pots[3])]
         gx = gy = None
-        with torch.no_grad():
-            hs = [logw + pot.reshape(B, -1) * (1.0 / eps) for _, _, logw, pot in specs]
-            vals = [(outs[i].reshape(B, -1) * (1.0 / damping)).contiguous() for i in range(k)]      # the soft-min values themselves
         for i, (rows, cols, logw, pot) in enumerate(specs):
             g = grads[i]
             if g is None or not ctx.needs_input_grad[i % 2]:
                 continue
-            gr = _bwd_x(rows.reshape(B, -1, rows.shape[-1]), g.reshape(B, -1) * damping, cols, hs[i], vals[i], eps, plan.p, None,
+            with torch.no_grad():      # (only for the reductions that take a gradient: a loss differentiated in x alone uses 2 of the 4 —
+                # the other two cost 6 launches of a launch-bound backward pass, round 6)
+                h_i = logw + pot.reshape(B, -1) * (1.0 / eps)
+                val_i = (outs[i].reshape(B, -1) * (1.0 / damping)).contiguous()      # the soft-min values themselves
+            gr = _bwd_x(rows.reshape(B, -1, rows.shape[-1]), g.reshape(B, -1) * damping, cols, h_i, val_i, eps, plan.p, None,
                         plan.flags | ctx.extra_flags).float()
             if i % 2 == 0:
                 gx = gr if gx is None else gx + gr
