@@ -40,6 +40,7 @@ leg trace_all - 900 bash tools/trace_all.sh                             # per-co
 leg accuracy_report gpurun_out/accuracy_report.txt 300 python tools/accuracy_report.py
 leg fuzz gpurun_out/fuzz.txt 200 python tools/fuzz_kernels.py 600 3
 leg fuzz_highd gpurun_out/fuzz_highd.txt 200 python tools/fuzz_highd.py 300 3
+leg fuzz_sparse gpurun_out/fuzz_sparse.txt 300 python tools/fuzz_sparse.py 300 3          # block-sparse forward (carried tiles, both layouts) and gradient
 leg small_probe gpurun_out/small_probe.txt 200 python tools/small_probe.py
 leg multiscale_pmc gpurun_out/multiscale_pmc.txt 600 env MIN_NS=5e6 PAIRS=2.1e11 bash tools/profile_kernels.sh ${TAG}_ms multiscale_1e6.py   # the block-sparse kernels of config 3
 leg raw_p1 gpurun_out/raw_p1_1e6.txt 200 python tools/raw_p1_1e6.py             # the self-sorting distance reductions through the raw C-ABI
