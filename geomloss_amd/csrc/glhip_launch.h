@@ -150,6 +150,9 @@ void launch_softmin_mfma_nw(const SoftminParams<T>& prm, const Ranges& rg, int n
     // whatever N is) — gather them into full tiles; clusters of hundreds of points already fill theirs
     sp.gather = (n_ranges > 0 && N / n_ranges < 128) ? 1 : 0;
     sp.share = (share && rgc.chunks) ? 1 : 0;
+    // 2-wavefront workgroups (small clusters): 12 of them are resident per CU, three times the 4-wavefront case choose_splits is
+    // tuned for — at least 6 splits (two-scale loss at N = 3e4 / 5e4 / 1e5: 2.11 / 3.01 / 5.30 -> 2.08 / 2.96 / 5.21 ms, three runs each)
+    if (NW == 2 && n_ranges > 0 && sc.allow_split && fit >= 6 && sp.n_splits > 1 && sp.n_splits < 6) sp.n_splits = 6;
 
     // Dense launches of the x32 kernel with enough work to pay for one more (tiny) launch split the columns into
     // bf16x3 MFMA records ONCE, in workspace behind the split partials, instead of once per workgroup.
